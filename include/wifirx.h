@@ -1,0 +1,214 @@
+/*
+ * wifirx.h -- C ABI of libwifirx.so: the MI355X-native IEEE 802.11a/g OFDM PHY receive chain.
+ *
+ * This is the drop-in boundary for the RX half of the reference's `wifi_phy_hier` hier block
+ * (gnu_radio/wifi_phy_hier.grc:100-260,480-569,698-768), which IRS_AP inlines block for block
+ * (gnu_radio/IRS_AP.py:267-285,291-311).  The reference has no FFI of its own for this path (its
+ * blocks are GNU Radio C++ objects reached through SWIG/pybind); a GNU Radio block that wants the
+ * GPU path binds exactly these entry points (ctypes stub in INTEGRATION.md).  Every function
+ * replaces the work() of the reference blocks named beside it.
+ *
+ * Plain C: pointers and sizes only, no torch / HIP types.  All functions return 0 on success or a
+ * negative WIFIRX_E* code; nothing throws across the boundary; no global state: every call works
+ * on a handle.  One handle = one stream of samples = one HIP stream; calls on one handle must be
+ * serialised by the caller, different handles are independent (GNU Radio runs each block on its
+ * own thread, so this matches the reference's threading).
+ *
+ * There is NO CPU fallback in this library: wifirx_create() fails with WIFIRX_ENODEV when no
+ * gfx950 device is usable.  The CPU restatement lives in oracle/ and is test infrastructure only.
+ */
+#ifndef WIFIRX_H
+#define WIFIRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WIFIRX_ABI_VERSION 1
+
+/* error codes */
+#define WIFIRX_OK        0
+#define WIFIRX_EINVAL   -1   /* bad argument */
+#define WIFIRX_ENODEV   -2   /* no usable HIP device / kernel image (gfx950) */
+#define WIFIRX_ENOMEM   -3   /* device or host allocation failed */
+#define WIFIRX_EHIP     -4   /* HIP runtime error (wifirx_last_error() has the text) */
+#define WIFIRX_ERANGE   -5   /* buffer too small / index out of range */
+
+/* Equalizer enum of the reference: ieee802_11.Equalizer (gnu_radio/IRS_AP.py:139-141). */
+#define WIFIRX_EQ_LS   0
+#define WIFIRX_EQ_LMS  1
+#define WIFIRX_EQ_COMB 2
+#define WIFIRX_EQ_STA  3
+
+/* Encoding enum of the reference: ieee802_11.Encoding (gnu_radio/IRS_user.py:130-132). */
+#define WIFIRX_BPSK_1_2   0
+#define WIFIRX_BPSK_3_4   1
+#define WIFIRX_QPSK_1_2   2
+#define WIFIRX_QPSK_3_4   3
+#define WIFIRX_16QAM_1_2  4
+#define WIFIRX_16QAM_3_4  5
+#define WIFIRX_64QAM_2_3  6
+#define WIFIRX_64QAM_3_4  7
+
+/* constants of the upstream blocks the chain follows */
+#define WIFIRX_SYNC_LENGTH   320     /* sync_long(sync_length), gnu_radio/wifi_phy_hier.grc:59-75 */
+#define WIFIRX_MIN_GAP       480     /* sync_short: re-trigger only after this many copied samples */
+#define WIFIRX_MAX_SAMPLES   (540 * 80)
+#define WIFIRX_MAX_SYM       511     /* decode_mac: frames with more data symbols are dropped */
+#define WIFIRX_MAX_PSDU      1528    /* decode_mac: MAX_PAYLOAD 1500 + 28 */
+
+/* frame flags */
+#define WIFIRX_F_DETECTED   0x01u   /* sync_short plateau found (trigger valid) */
+#define WIFIRX_F_SYNC       0x02u   /* sync_long found an LTS peak pair (frame_start, cfo_fine valid) */
+#define WIFIRX_F_SIGNAL     0x04u   /* SIGNAL field decoded: parity ok and known rate */
+#define WIFIRX_F_COMPLETE   0x08u   /* all n_sym data symbols lie inside the available samples and the
+                                       output capacity (max_sym) and were written */
+#define WIFIRX_F_LLR        0x10u   /* LLRs written for this frame (n_bpsc <= llr_bits) */
+#define WIFIRX_F_DECODED    0x20u   /* decode_mac ran (Viterbi + descramble) */
+#define WIFIRX_F_CRC_OK     0x40u   /* FCS good: PSDU delivered */
+
+/* One record per slot (batch mode) or per detected frame (stream mode): the stream tags
+ * `wifi_start` of sync_short / sync_long / frame_equalizer rolled into one. */
+typedef struct wifirx_frame {
+    uint32_t flags;
+    int32_t  trigger;      /* index n (in the slot / the stream) of the sync_short trigger sample of
+                              the 16-delayed input, -1 if none; first copied sample is x[trigger-16] */
+    int32_t  frame_start;  /* sync_long d_frame_start: offset of LTS1 in the copied samples (0..320) */
+    float    cfo_coarse;   /* sync_short:  arg(A[trigger])/16          rad/sample */
+    float    cfo_fine;     /* sync_long:   arg(p1*conj(p2))/64         rad/sample (upstream sign) */
+    float    snr_db;       /* LS equalizer SNR estimate from LTS1/LTS2 */
+    uint16_t psdu_len;     /* SIGNAL LENGTH ("frame_bytes") */
+    uint8_t  encoding;     /* WIFIRX_BPSK_1_2 .. WIFIRX_64QAM_3_4 */
+    uint8_t  n_bpsc;       /* bits per sub-carrier of `encoding` */
+    uint16_t n_sym;        /* data symbols the SIGNAL field announces */
+    uint16_t n_sym_out;    /* data symbols actually demodulated into the output buffers */
+} wifirx_frame;            /* 32 bytes */
+
+typedef struct wifirx_config {
+    uint32_t abi_version;  /* WIFIRX_ABI_VERSION */
+    int32_t  device;       /* HIP device ordinal */
+    double   bandwidth;    /* sample rate in Hz: wifi_phy_hier `bandwidth` (grc:83-92) */
+    double   frequency;    /* carrier in Hz:    wifi_phy_hier `frequency` (grc:501-510) */
+    float    sensitivity;  /* sync_short threshold: wifi_phy_hier `sensitivity` (grc:681-690), 0.56 */
+    int32_t  min_plateau;  /* sync_short min_plateau, 2 (gnu_radio/IRS_AP.py:268) */
+    int32_t  chan_est;     /* WIFIRX_EQ_*: wifi_phy_hier `chan_est` (grc:299-308); LS implemented */
+    uint32_t max_sym;      /* output capacity per frame in data symbols (<= WIFIRX_MAX_SYM) */
+    uint32_t llr_bits;     /* LLR capacity per sub-carrier (0 = no LLR output, else 1,2,4,6) */
+    uint32_t want_carrier; /* 1: also write the 48 equalised points per symbol (`carrier` port) */
+    uint32_t max_batch;    /* largest n_slots of a wifirx_demod_batch call (workspace size) */
+    uint32_t max_slot_len; /* largest slot length in samples */
+} wifirx_config;
+
+/* parameter ids for wifirx_set_param: the setters the reference flowgraphs call
+ * (gnu_radio/IRS_user.py:229,265,273; gnu_radio/IRS_AP.py:348,373,382) */
+#define WIFIRX_P_BANDWIDTH   1
+#define WIFIRX_P_FREQUENCY   2
+#define WIFIRX_P_SENSITIVITY 3
+#define WIFIRX_P_CHAN_EST    4
+
+typedef struct wifirx_handle wifirx_handle;
+
+/* Output buffers of a batch call.  Every pointer is caller-owned DEVICE memory when
+ * `on_device` != 0, HOST memory otherwise (the library then stages through its own device
+ * buffers; that path is PCIe-bound and is not the measured one).  NULL = do not produce.
+ *   frames  [n_slots]
+ *   idx     [n_slots][max_sym][48]            hard decisions, one constellation index per byte
+ *                                              (output 0 of frame_equalizer, grc:550-569)
+ *   llr     [n_slots][max_sym*48*llr_bits]    per frame packed [sym][carrier][bit 0..n_bpsc-1]
+ *   carrier [n_slots][max_sym][48][2]         equalised points (re,im): the `symbols` message port
+ *   psdu    [n_slots][psdu_stride]            decode_mac output: MAC frame incl. FCS position
+ *                                              (bytes 0..psdu_len-1), valid when WIFIRX_F_CRC_OK
+ */
+typedef struct wifirx_out {
+    wifirx_frame* frames;
+    uint8_t*      idx;
+    float*        llr;
+    float*        carrier;
+    uint8_t*      psdu;
+    uint32_t      psdu_stride;  /* bytes per slot in `psdu` (>= largest psdu_len expected) */
+    uint32_t      on_device;
+} wifirx_out;
+
+typedef struct wifirx_stats {
+    uint64_t samples_in;     /* samples consumed */
+    uint64_t frames_detected;
+    uint64_t frames_signal_ok;
+    uint64_t frames_complete;
+    uint64_t frames_crc_ok;
+    uint64_t frames_dropped; /* detected but not delivered (sync / SIGNAL / truncation / CRC) */
+} wifirx_stats;
+
+/* lifetime ------------------------------------------------------------------------------------ */
+int  wifirx_create(const wifirx_config* cfg, wifirx_handle** out);
+int  wifirx_destroy(wifirx_handle* h);
+const char* wifirx_last_error(const wifirx_handle* h);      /* never NULL */
+int  wifirx_abi_version(void);
+
+/* replaces the generated set_bandwidth/set_frequency/set_chan_est/set_sensitivity setters */
+int  wifirx_set_param(wifirx_handle* h, int id, double value);
+int  wifirx_get_stats(const wifirx_handle* h, wifirx_stats* st);
+
+/* Batch mode: n_slots independent slots of slot_len samples each, laid out back to back in `iq`
+ * (interleaved float re,im = complex64 / GNU Radio gr_complex).  Every slot is treated as its own
+ * sample stream that starts in sync_short's SEARCH state; the first frame of every slot is
+ * demodulated:  autocorrelation graph + sync_short + sync_long + fft_vcc + frame_equalizer
+ * (gnu_radio/IRS_AP.py:268-269,271,273,276-285).  Asynchronous on the handle's stream when all
+ * buffers are on the device; call wifirx_sync() before reading results. */
+int  wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device,
+                        uint32_t slot_len, uint32_t n_slots, const wifirx_out* out);
+
+/* decode_mac over the hard decisions of a previous wifirx_demod_batch on the same buffers
+ * (ieee802_11.decode_mac, gnu_radio/IRS_AP.py:272,291-292): de-interleave, de-puncture, Viterbi
+ * K=7 (133,171), descramble, CRC-32.  Sets WIFIRX_F_DECODED / WIFIRX_F_CRC_OK in out->frames
+ * and writes out->psdu. */
+int  wifirx_decode_batch(wifirx_handle* h, uint32_t n_slots, const wifirx_out* out);
+
+/* Stream mode (what the GNU Radio block's work() calls): append `n` samples of the continuous
+ * input stream (host or device memory; the library copies).  Frames that completed inside the
+ * samples seen so far are demodulated + decoded and queued for wifirx_poll. */
+int  wifirx_push(wifirx_handle* h, const float* iq, size_t n, int iq_on_device);
+
+/* Fetch up to `cap` queued frames (host memory).  For frame i: record frames[i], its PSDU at
+ * psdu + i*psdu_stride, and -- when requested at create time and the pointers are non-NULL --
+ * its hard decisions at idx + i*max_sym*48 and equalised points at carrier + i*max_sym*96 floats.
+ * *n_out receives the number of frames written. */
+int  wifirx_poll(wifirx_handle* h, wifirx_frame* frames, uint8_t* psdu, uint32_t psdu_stride,
+                 uint8_t* idx, float* carrier, uint32_t cap, uint32_t* n_out);
+
+/* block until everything queued on the handle's stream has finished */
+int  wifirx_sync(wifirx_handle* h);
+
+/* The HIP stream of the handle as an opaque pointer (hipStream_t), so that a caller can record
+ * events / order its own work against it. */
+void* wifirx_stream(wifirx_handle* h);
+
+/* Synthetic channel on the device (test bench of gnu_radio/IRS_tranceiver.py:282-294): builds
+ * n_slots slots from n_templates clean frames (host or device memory, frame_len samples each, frame
+ * i uses template i % n_templates): slot = noise(unit variance, Philox counter RNG, `seed`) with
+ * the frame scaled by sqrt(10^(snr_db/10)) and rotated by a per-slot CFO drawn uniformly from
+ * +-cfo_max rad/sample, placed `lead` samples into the slot.  Writes `cfo_out[n_slots]` when
+ * non-NULL.  Output `slots` is device memory of n_slots*slot_len complex64. */
+int  wifirx_synth_slots(wifirx_handle* h, const float* templates, int templates_on_device,
+                        uint32_t n_templates, uint32_t frame_len, float* slots, uint32_t slot_len,
+                        uint32_t n_slots, uint32_t lead, float snr_db, float cfo_max,
+                        uint64_t seed, float* cfo_out);
+
+/* plain device memory helpers so that a host language without a HIP binding can own buffers */
+int  wifirx_dev_alloc(wifirx_handle* h, size_t bytes, void** out);
+int  wifirx_dev_free(wifirx_handle* h, void* p);
+int  wifirx_memcpy_h2d(wifirx_handle* h, void* dst, const void* src, size_t bytes);
+int  wifirx_memcpy_d2h(wifirx_handle* h, void* dst, const void* src, size_t bytes);
+
+/* Time the dominant kernel of wifirx_demod_batch with HIP events on the handle's stream: runs the
+ * batch `iters` times and returns the mean kernel time in milliseconds (used by bench.py for
+ * roofline.achieved). */
+int  wifirx_time_demod(wifirx_handle* h, const float* iq_dev, uint32_t slot_len, uint32_t n_slots,
+                       const wifirx_out* out, int iters, float* ms_mean);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WIFIRX_H */
