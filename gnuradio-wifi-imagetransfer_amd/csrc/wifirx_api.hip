@@ -1,0 +1,359 @@
+// wifirx_api.hip -- implementation of the C ABI in include/wifirx.h on top of the HIP kernels.
+// Host side only: handles, the per-handle HIP stream, workspaces, host<->device staging.
+// No CPU compute fallback exists: every entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "wifirx.h"
+#include "wr_kernels.h"
+
+struct PolledFrame {
+    wifirx_frame          fr;
+    std::vector<uint8_t>  psdu;
+    std::vector<uint8_t>  idx;
+    std::vector<float>    carrier;
+};
+
+struct PendingTrig {
+    int64_t pos;   // absolute stream index of the trigger
+    float   cfo;
+};
+
+struct wifirx_handle {
+    wifirx_config cfg;
+    int           device = 0;
+    hipStream_t   stream = nullptr;
+    std::string   err;
+    wifirx_stats  stats{};
+
+    // batch staging (host-buffer path only)
+    void*  stage_iq = nullptr;      size_t stage_iq_bytes = 0;
+    void*  stage_frames = nullptr;  size_t stage_frames_bytes = 0;
+    void*  stage_idx = nullptr;     size_t stage_idx_bytes = 0;
+    void*  stage_llr = nullptr;     size_t stage_llr_bytes = 0;
+    void*  stage_car = nullptr;     size_t stage_car_bytes = 0;
+    void*  stage_psdu = nullptr;    size_t stage_psdu_bytes = 0;
+
+    // decode workspace
+    void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;  size_t dec_scratch_stride = 0;
+
+    // stream mode
+    float2*  sbuf = nullptr;        int64_t sbuf_cap = 0;     // device sample buffer
+    int64_t  sbase = 0;             // absolute index of sbuf[0] (multiple of 64)
+    int64_t  sfill = 0;             // valid samples in sbuf
+    int64_t  sdetected = 0;         // absolute index up to which triggers have been selected
+    int64_t  last_trig = -(1ll << 40);
+    uint8_t* s_above = nullptr;     float2* s_A = nullptr;    int64_t s_above_cap = 0;
+    std::vector<PendingTrig> pending;
+    std::deque<PolledFrame>  queue;
+    void*  s_trig = nullptr;  void* s_frames = nullptr;  void* s_idx = nullptr;  void* s_llr = nullptr;
+    void*  s_car = nullptr;   void* s_psdu = nullptr;    uint32_t s_cap = 0;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(wifirx_handle* h, int code, const std::string& msg)
+{
+    if (h) h->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, WIFIRX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+int ensure(wifirx_handle* h, void** p, size_t* have, size_t need)
+{
+    if (*have >= need) return WIFIRX_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    *have = need;
+    return WIFIRX_OK;
+}
+
+wr::DemodParams params_of(const wifirx_handle* h)
+{
+    wr::DemodParams p;
+    p.bandwidth = h->cfg.bandwidth;
+    p.frequency = h->cfg.frequency;
+    p.threshold = h->cfg.sensitivity;
+    p.min_plateau = h->cfg.min_plateau;
+    p.max_sym = h->cfg.max_sym;
+    p.llr_bits = h->cfg.llr_bits;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wifirx_abi_version(void) { return WIFIRX_ABI_VERSION; }
+
+const char* wifirx_last_error(const wifirx_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
+{
+    if (!cfg || !out) return fail(nullptr, WIFIRX_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != WIFIRX_ABI_VERSION) return fail(nullptr, WIFIRX_EINVAL, "abi_version mismatch");
+    if (cfg->max_sym == 0 || cfg->max_sym > WIFIRX_MAX_SYM) return fail(nullptr, WIFIRX_EINVAL, "max_sym out of range");
+    if (!(cfg->llr_bits == 0 || cfg->llr_bits == 1 || cfg->llr_bits == 2 || cfg->llr_bits == 4 || cfg->llr_bits == 6))
+        return fail(nullptr, WIFIRX_EINVAL, "llr_bits must be 0,1,2,4,6");
+    if (cfg->chan_est != WIFIRX_EQ_LS) return fail(nullptr, WIFIRX_EINVAL, "only the LS equalizer is implemented");
+    if (!(cfg->bandwidth > 0) || !(cfg->frequency > 0)) return fail(nullptr, WIFIRX_EINVAL, "bandwidth/frequency must be > 0");
+    if (cfg->min_plateau < 0 || cfg->min_plateau > 32) return fail(nullptr, WIFIRX_EINVAL, "min_plateau out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, WIFIRX_ENODEV, "no HIP device: libwifirx has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, WIFIRX_ENODEV, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, WIFIRX_ENODEV, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, WIFIRX_ENODEV, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    wifirx_handle* h = new (std::nothrow) wifirx_handle();
+    if (!h) return fail(nullptr, WIFIRX_ENOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(nullptr, WIFIRX_EHIP, "hipStreamCreate failed");
+    }
+    *out = h;
+    return WIFIRX_OK;
+}
+
+int wifirx_destroy(wifirx_handle* h)
+{
+    if (!h) return WIFIRX_EINVAL;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu,
+                     h->dec_scratch, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx, h->s_llr,
+                     h->s_car, h->s_psdu };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return WIFIRX_OK;
+}
+
+int wifirx_set_param(wifirx_handle* h, int id, double value)
+{
+    if (!h) return WIFIRX_EINVAL;
+    switch (id) {
+    case WIFIRX_P_BANDWIDTH:
+        if (!(value > 0)) return fail(h, WIFIRX_EINVAL, "bandwidth must be > 0");
+        h->cfg.bandwidth = value;
+        return WIFIRX_OK;
+    case WIFIRX_P_FREQUENCY:
+        if (!(value > 0)) return fail(h, WIFIRX_EINVAL, "frequency must be > 0");
+        h->cfg.frequency = value;
+        return WIFIRX_OK;
+    case WIFIRX_P_SENSITIVITY:
+        h->cfg.sensitivity = (float)value;
+        return WIFIRX_OK;
+    case WIFIRX_P_CHAN_EST:
+        if ((int)value != WIFIRX_EQ_LS) return fail(h, WIFIRX_EINVAL, "only the LS equalizer is implemented");
+        h->cfg.chan_est = (int)value;
+        return WIFIRX_OK;
+    default:
+        return fail(h, WIFIRX_EINVAL, "unknown parameter id");
+    }
+}
+
+int wifirx_get_stats(const wifirx_handle* h, wifirx_stats* st)
+{
+    if (!h || !st) return WIFIRX_EINVAL;
+    *st = h->stats;
+    return WIFIRX_OK;
+}
+
+void* wifirx_stream(wifirx_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int wifirx_sync(wifirx_handle* h)
+{
+    if (!h) return WIFIRX_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return WIFIRX_OK;
+}
+
+int wifirx_dev_alloc(wifirx_handle* h, size_t bytes, void** out)
+{
+    if (!h || !out) return WIFIRX_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return WIFIRX_OK;
+}
+
+int wifirx_dev_free(wifirx_handle* h, void* p)
+{
+    if (!h) return WIFIRX_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipFree(p));
+    return WIFIRX_OK;
+}
+
+int wifirx_memcpy_h2d(wifirx_handle* h, void* dst, const void* src, size_t bytes)
+{
+    if (!h) return WIFIRX_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return WIFIRX_OK;
+}
+
+int wifirx_memcpy_d2h(wifirx_handle* h, void* dst, const void* src, size_t bytes)
+{
+    if (!h) return WIFIRX_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return WIFIRX_OK;
+}
+
+// ---- batch mode -----------------------------------------------------------------------------
+
+static int check_batch(wifirx_handle* h, uint32_t slot_len, uint32_t n_slots, const wifirx_out* out)
+{
+    if (!h || !out) return WIFIRX_EINVAL;
+    if (!out->frames) return fail(h, WIFIRX_EINVAL, "out->frames is required");
+    if (slot_len == 0) return fail(h, WIFIRX_EINVAL, "slot_len must be > 0");
+    if (h->cfg.max_batch && n_slots > h->cfg.max_batch) return fail(h, WIFIRX_ERANGE, "n_slots exceeds max_batch");
+    if (h->cfg.max_slot_len && slot_len > h->cfg.max_slot_len) return fail(h, WIFIRX_ERANGE, "slot_len exceeds max_slot_len");
+    if (out->llr && h->cfg.llr_bits == 0) return fail(h, WIFIRX_EINVAL, "llr requested but llr_bits == 0");
+    return WIFIRX_OK;
+}
+
+int wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device, uint32_t slot_len,
+                       uint32_t n_slots, const wifirx_out* out)
+{
+    int rc = check_batch(h, slot_len, n_slots, out);
+    if (rc) return rc;
+    if (!iq) return fail(h, WIFIRX_EINVAL, "iq is null");
+    if (n_slots == 0) return WIFIRX_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const wr::DemodParams prm = params_of(h);
+    const size_t n_iq = (size_t)slot_len * n_slots;
+    const size_t idx_n = (size_t)n_slots * h->cfg.max_sym * 48;
+    const float2* d_iq = reinterpret_cast<const float2*>(iq);
+    if (!iq_on_device) {
+        if ((rc = ensure(h, &h->stage_iq, &h->stage_iq_bytes, n_iq * sizeof(float2)))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->stage_iq, iq, n_iq * sizeof(float2), hipMemcpyHostToDevice, h->stream));
+        d_iq = reinterpret_cast<const float2*>(h->stage_iq);
+    }
+    wifirx_frame* d_fr = out->frames;
+    uint8_t* d_idx = out->idx;
+    float*   d_llr = out->llr;
+    float2*  d_car = reinterpret_cast<float2*>(out->carrier);
+    if (!out->on_device) {
+        if ((rc = ensure(h, &h->stage_frames, &h->stage_frames_bytes, n_slots * sizeof(wifirx_frame)))) return rc;
+        d_fr = reinterpret_cast<wifirx_frame*>(h->stage_frames);
+        if (out->idx) {
+            if ((rc = ensure(h, &h->stage_idx, &h->stage_idx_bytes, idx_n))) return rc;
+            d_idx = reinterpret_cast<uint8_t*>(h->stage_idx);
+            HIP_TRY(h, hipMemsetAsync(d_idx, 0, idx_n, h->stream));
+        }
+        if (out->llr) {
+            if ((rc = ensure(h, &h->stage_llr, &h->stage_llr_bytes, idx_n * h->cfg.llr_bits * sizeof(float)))) return rc;
+            d_llr = reinterpret_cast<float*>(h->stage_llr);
+            HIP_TRY(h, hipMemsetAsync(d_llr, 0, idx_n * h->cfg.llr_bits * sizeof(float), h->stream));
+        }
+        if (out->carrier) {
+            if ((rc = ensure(h, &h->stage_car, &h->stage_car_bytes, idx_n * sizeof(float2)))) return rc;
+            d_car = reinterpret_cast<float2*>(h->stage_car);
+            HIP_TRY(h, hipMemsetAsync(d_car, 0, idx_n * sizeof(float2), h->stream));
+        }
+    }
+    HIP_TRY(h, wr_launch_demod_batch(h->stream, d_iq, slot_len, n_slots, &prm, d_fr, d_idx, d_llr, d_car));
+    h->stats.samples_in += n_iq;
+    if (!out->on_device) {
+        HIP_TRY(h, hipMemcpyAsync(out->frames, d_fr, n_slots * sizeof(wifirx_frame), hipMemcpyDeviceToHost, h->stream));
+        if (out->idx) HIP_TRY(h, hipMemcpyAsync(out->idx, d_idx, idx_n, hipMemcpyDeviceToHost, h->stream));
+        if (out->llr) HIP_TRY(h, hipMemcpyAsync(out->llr, d_llr, idx_n * h->cfg.llr_bits * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        if (out->carrier) HIP_TRY(h, hipMemcpyAsync(out->carrier, d_car, idx_n * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (uint32_t i = 0; i < n_slots; i++) {
+            uint32_t f = out->frames[i].flags;
+            h->stats.frames_detected += (f & WIFIRX_F_DETECTED) != 0;
+            h->stats.frames_signal_ok += (f & WIFIRX_F_SIGNAL) != 0;
+            h->stats.frames_complete += (f & WIFIRX_F_COMPLETE) != 0;
+        }
+    }
+    return WIFIRX_OK;
+}
+
+int wifirx_time_demod(wifirx_handle* h, const float* iq_dev, uint32_t slot_len, uint32_t n_slots,
+                      const wifirx_out* out, int iters, float* ms_mean)
+{
+    int rc = check_batch(h, slot_len, n_slots, out);
+    if (rc) return rc;
+    if (!iq_dev || !ms_mean || iters <= 0 || !out->on_device) return fail(h, WIFIRX_EINVAL, "device buffers and iters > 0 required");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const wr::DemodParams prm = params_of(h);
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    double total = 0;
+    for (int i = 0; i < iters; i++) {
+        HIP_TRY(h, hipEventRecord(e0, h->stream));
+        HIP_TRY(h, wr_launch_demod_batch(h->stream, reinterpret_cast<const float2*>(iq_dev), slot_len, n_slots, &prm,
+                                         out->frames, out->idx, out->llr, reinterpret_cast<float2*>(out->carrier)));
+        HIP_TRY(h, hipEventRecord(e1, h->stream));
+        HIP_TRY(h, hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+        total += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_mean = (float)(total / iters);
+    return WIFIRX_OK;
+}
+
+int wifirx_synth_slots(wifirx_handle* h, const float* templates, int templates_on_device, uint32_t n_templates,
+                       uint32_t frame_len, float* slots, uint32_t slot_len, uint32_t n_slots, uint32_t lead,
+                       float snr_db, float cfo_max, uint64_t seed, float* cfo_out)
+{
+    if (!h || !templates || !slots) return WIFIRX_EINVAL;
+    if (n_templates == 0 || frame_len == 0) return fail(h, WIFIRX_EINVAL, "empty templates");
+    if (slot_len % 2) return fail(h, WIFIRX_EINVAL, "slot_len must be even");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const float2* d_t = reinterpret_cast<const float2*>(templates);
+    void* tmp = nullptr;
+    if (!templates_on_device) {
+        size_t bytes = (size_t)n_templates * frame_len * sizeof(float2);
+        hipError_t e = hipMalloc(&tmp, bytes);
+        if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, "hipMalloc(templates)");
+        HIP_TRY(h, hipMemcpyAsync(tmp, templates, bytes, hipMemcpyHostToDevice, h->stream));
+        d_t = reinterpret_cast<const float2*>(tmp);
+    }
+    float gain = std::sqrt(std::pow(10.0f, snr_db / 10.0f));
+    hipError_t e = wr_launch_synth(h->stream, d_t, n_templates, frame_len, reinterpret_cast<float2*>(slots), slot_len,
+                                   n_slots, lead, gain, cfo_max, seed, cfo_out);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(h, WIFIRX_EHIP, std::string("synth launch: ") + hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(h, WIFIRX_EHIP, std::string("synth sync: ") + hipGetErrorString(e2));
+    return WIFIRX_OK;
+}
+
+}  // extern "C"
+
+#include "wifirx_api_decode.inc"
+#include "wifirx_api_stream.inc"

@@ -1,0 +1,47 @@
+// wr_kernels.h -- host-visible launch interface of the wifirx HIP kernels (internal, not the C ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wifirx.h"
+
+#define WR_WAVES_PER_BLOCK 4
+#define WR_YLDS_FLOATS     768      // 384 complex: the 383 coarse-derotated samples sync_long correlates
+
+namespace wr {
+
+struct DemodParams {
+    double   bandwidth;
+    double   frequency;
+    float    threshold;
+    int32_t  min_plateau;
+    uint32_t max_sym;
+    uint32_t llr_bits;
+};
+
+// one detected frame of a continuous stream (stream mode)
+struct StreamTrig {
+    int64_t pos;        // trigger index in the stream buffer
+    int64_t usable;     // L: copied samples that belong to this trigger
+    float   cfo;        // coarse CFO
+    int32_t pad;
+};
+
+}  // namespace wr
+
+extern "C" {
+hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot_len, uint32_t n_slots,
+                                 const wr::DemodParams* prm, wifirx_frame* frames, uint8_t* idx,
+                                 float* llr, float2* carrier);
+hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_templates, uint32_t frame_len,
+                           float2* slots, uint32_t slot_len, uint32_t n_slots, uint32_t lead, float gain,
+                           float cfo_max, uint64_t seed, float* cfo_out);
+hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
+                            const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
+                            size_t scratch_stride);
+hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_samp, int64_t n_valid_from,
+                                   float thr, uint8_t* above, float2* A);
+hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
+                                  uint32_t n_trig, const wr::DemodParams* prm, wifirx_frame* frames,
+                                  uint8_t* idx, float* llr, float2* carrier);
+}
