@@ -7,6 +7,7 @@
 
 #define WR_WAVES_PER_BLOCK 4
 #define WR_YLDS_FLOATS     768      // 384 complex: the 383 coarse-derotated samples sync_long correlates
+#define WR_DECODE_MAX_WAVES 8192    // resident waves of the decode kernel (each owns a scratch slice)
 
 namespace wr {
 

@@ -37,3 +37,29 @@ def test_batch_bit_exact_all_rates(capi, orc, encoding):
     assert (o["frames"]["flags"] & orc.F_COMPLETE).all()
     _compare(r, o, 6)
     rx.close()
+
+
+@pytest.mark.parametrize("encoding,snr", [(0, 25), (1, 25), (2, 25), (3, 25), (4, 25), (5, 25), (6, 28), (7, 28),
+                                          (2, 4.0), (5, 14.0), (7, 19.0)])
+def test_decode_mac_bit_exact(capi, orc, encoding, snr):
+    """decode_mac (Viterbi, descramble, CRC) on the device == oracle, also where the channel
+    leaves bit errors (survivor tie-breaks must agree)."""
+    iq, slot_len, tx = make_slots(40, encoding, snr_db=snr, seed=100 + encoding)
+    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=0)
+    r = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=320)
+    prm = orc.make_params(max_sym=tx.n_sym)
+    o = orc.demod_batch(iq, slot_len, prm)
+    opsdu = orc.decode_batch(o["frames"], o["idx"], prm, psdu_stride=320)
+    assert np.array_equal(r["frames"], o["frames"])
+    dec = (o["frames"]["flags"] & orc.F_DECODED) != 0
+    assert np.array_equal(r["psdu"][dec][:, :294], opsdu[dec][:, :294])
+    ok = (o["frames"]["flags"] & orc.F_CRC_OK) != 0
+    if snr >= 25:
+        assert ok.all()
+        assert np.array_equal(r["psdu"][:, :294], tx.psdu)
+    rx.close()
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
