@@ -23,8 +23,9 @@ struct PolledFrame {
 };
 
 struct PendingTrig {
-    int64_t pos;   // absolute stream index of the trigger
-    float   cfo;
+    int64_t pos;        // absolute stream index of the trigger
+    float   cfo;        // coarse CFO, valid once the frame kernel has seen the trigger (have_cfo)
+    bool    have_cfo;
 };
 
 struct wifirx_handle {

@@ -7,6 +7,7 @@
 
 #define WR_WAVES_PER_BLOCK 4
 #define WR_YLDS_FLOATS     768      // 384 complex: the 383 coarse-derotated samples sync_long correlates
+#define WR_STREAM_SPAN     16       // tiles of 64 samples one wave scans in stream-mode detection
 #define WR_DECODE_MAX_WAVES 8192    // resident waves of the decode kernel (each owns a scratch slice)
 
 namespace wr {
@@ -40,9 +41,9 @@ hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_t
 hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                             const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
                             size_t scratch_stride);
-hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_samp, int64_t n_valid_from,
-                                   float thr, uint8_t* above, float2* A);
+hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_samp, int64_t tile0,
+                                   int64_t n_tiles, float thr, uint64_t* masks, float2* A);
 hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
-                                  uint32_t n_trig, const wr::DemodParams* prm, wifirx_frame* frames,
-                                  uint8_t* idx, float* llr, float2* carrier);
+                                  uint32_t n_trig, const wr::DemodParams* prm, const float2* A,
+                                  wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier);
 }

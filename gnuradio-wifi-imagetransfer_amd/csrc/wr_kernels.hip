@@ -182,63 +182,85 @@ __device__ __forceinline__ bool parse_signal(uint32_t bits, int& enc, int& len)
 }
 
 // ---------------------------------------------------------------------------------------------
-// detect phase: first sync_short trigger of a slot.  Returns the trigger index or -1; A_t = A[trigger].
-__device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n_samp, float thr,
-                                            int min_plateau, int lane, c32& A_t)
+// detect phase (a1 + a2).  One tile = 64 consecutive samples, lane <-> sample; the window sums
+// follow the blocked scheme of the spec (section 4.2): Kogge-Stone prefix H / exclusive suffix T inside
+// blocks of 16 lanes (DPP row shifts), block totals and tails of the 3-4 previous blocks.
+struct DetectState {       // what a tile needs from the tile before it
+    float Hr, Hi, Hp, Tr, Ti, Tp;
+};
+
+__device__ __forceinline__ DetectState detect_state_zero() { return { 0, 0, 0, 0, 0, 0 }; }
+
+// Processes tile [n0, n0+64).  Returns the ballot of c[n] > thr; Ar/Ai = A[n] of this lane's sample.
+__device__ __forceinline__ uint64_t detect_tile(const float2* __restrict__ x, long n_samp, long n0, float thr,
+                                                int lane, DetectState& ps, float& Ar, float& Ai)
 {
-    // prefix H, exclusive suffix T of the previous tile (blocks m-4..m-1 of the first row)
-    float pHr = 0, pHi = 0, pHp = 0, pTr = 0, pTi = 0, pTp = 0;
-    uint64_t prev_mask = 0;
     const int q = lane >> 4;
     const int l16 = (lane + 16) & 63;              // lane that holds index lane-48 (mod 64)
     const int b1 = (((q - 1) & 3) << 4) | 15;      // last lane of block m-1 / m-2 / m-3
     const int b2 = (((q - 2) & 3) << 4) | 15;
     const int b3 = (((q - 3) & 3) << 4) | 15;
+    long n = n0 + lane;
+    c32 xn = load_sample(x, n, n_samp);
+    c32 xd = load_sample(x, n - 16, n_samp);
+    float ar = fma_(xn.im, xd.im, xn.re * xd.re);
+    float ai = fma_(xn.im, xd.re, -(xn.re * xd.im));
+    float pw = fma_(xn.im, xn.im, xn.re * xn.re);
+    float Hr = row_prefix16(ar), Hi = row_prefix16(ai), Hp = row_prefix16(pw);
+    float Tr = dpp_zero<0x101>(row_suffix16(ar));
+    float Ti = dpp_zero<0x101>(row_suffix16(ai));
+    float Tp = dpp_zero<0x101>(row_suffix16(pw));
+    // Every shuffle is issued by all 64 lanes (a shuffle under a divergent condition would read
+    // inactive source lanes); the choice between this tile and the previous one is a select.
+    float cT3r = shfl(Tr, l16), oT3r = shfl(ps.Tr, l16), cT3i = shfl(Ti, l16), oT3i = shfl(ps.Ti, l16);
+    float cB2r = shfl(Hr, b2), oB2r = shfl(ps.Hr, b2), cB2i = shfl(Hi, b2), oB2i = shfl(ps.Hi, b2);
+    float cB1r = shfl(Hr, b1), oB1r = shfl(ps.Hr, b1), cB1i = shfl(Hi, b1), oB1i = shfl(ps.Hi, b1);
+    float cB3p = shfl(Hp, b3), oB3p = shfl(ps.Hp, b3);
+    float cB2p = shfl(Hp, b2), oB2p = shfl(ps.Hp, b2);
+    float cB1p = shfl(Hp, b1), oB1p = shfl(ps.Hp, b1);
+    float t3r = (q >= 3) ? cT3r : oT3r;            // tail of block m-3 at the same r
+    float t3i = (q >= 3) ? cT3i : oT3i;
+    float B2r = (q >= 2) ? cB2r : oB2r;
+    float B2i = (q >= 2) ? cB2i : oB2i;
+    float B1r = (q >= 1) ? cB1r : oB1r;
+    float B1i = (q >= 1) ? cB1i : oB1i;
+    float B3p = (q >= 3) ? cB3p : oB3p;
+    float B2p = (q >= 2) ? cB2p : oB2p;
+    float B1p = (q >= 1) ? cB1p : oB1p;
+    Ar = ((t3r + B2r) + B1r) + Hr;
+    Ai = ((t3i + B2i) + B1i) + Hi;
+    float P  = (((ps.Tp + B3p) + B2p) + B1p) + Hp; // tail of block m-4: same lane, previous tile
+    float m2 = fma_(Ai, Ai, Ar * Ar);
+    float tp = thr * P;
+    bool above = (m2 > tp * tp) && (n < n_samp);
+    ps = { Hr, Hi, Hp, Tr, Ti, Tp };
+    return __ballot(above);
+}
+
+// positions where c > thr held for min_plateau+1 consecutive samples ending there
+__device__ __forceinline__ uint64_t plateau_hits(uint64_t mask, uint64_t prev_mask, int min_plateau)
+{
+    uint64_t hit = mask;
+    for (int j = 1; j <= min_plateau; j++) hit &= (mask << j) | (prev_mask >> (64 - j));
+    return hit;
+}
+
+// first sync_short trigger of a slot.  Returns the trigger index or -1; A_t = A[trigger].
+__device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n_samp, float thr,
+                                            int min_plateau, int lane, c32& A_t)
+{
+    DetectState ps = detect_state_zero();
+    uint64_t prev_mask = 0;
     for (long n0 = 0; n0 < n_samp; n0 += 64) {
-        long n = n0 + lane;
-        c32 xn = load_sample(x, n, n_samp);
-        c32 xd = load_sample(x, n - 16, n_samp);
-        float ar = fma_(xn.im, xd.im, xn.re * xd.re);
-        float ai = fma_(xn.im, xd.re, -(xn.re * xd.im));
-        float pw = fma_(xn.im, xn.im, xn.re * xn.re);
-        float Hr = row_prefix16(ar), Hi = row_prefix16(ai), Hp = row_prefix16(pw);
-        float Tr = dpp_zero<0x101>(row_suffix16(ar));
-        float Ti = dpp_zero<0x101>(row_suffix16(ai));
-        float Tp = dpp_zero<0x101>(row_suffix16(pw));
-        // tail of block m-3 (for A) at the same r: element lane-48 of [prev | cur].
-        // Every shuffle is issued by all 64 lanes (a shuffle under a divergent condition would
-        // read inactive source lanes), the choice between the two tiles is a select afterwards.
-        float cT3r = shfl(Tr, l16), oT3r = shfl(pTr, l16), cT3i = shfl(Ti, l16), oT3i = shfl(pTi, l16);
-        float cB2r = shfl(Hr, b2), oB2r = shfl(pHr, b2), cB2i = shfl(Hi, b2), oB2i = shfl(pHi, b2);
-        float cB1r = shfl(Hr, b1), oB1r = shfl(pHr, b1), cB1i = shfl(Hi, b1), oB1i = shfl(pHi, b1);
-        float cB3p = shfl(Hp, b3), oB3p = shfl(pHp, b3);
-        float cB2p = shfl(Hp, b2), oB2p = shfl(pHp, b2);
-        float cB1p = shfl(Hp, b1), oB1p = shfl(pHp, b1);
-        float t3r = (q >= 3) ? cT3r : oT3r;
-        float t3i = (q >= 3) ? cT3i : oT3i;
-        float B2r = (q >= 2) ? cB2r : oB2r;
-        float B2i = (q >= 2) ? cB2i : oB2i;
-        float B1r = (q >= 1) ? cB1r : oB1r;
-        float B1i = (q >= 1) ? cB1i : oB1i;
-        float B3p = (q >= 3) ? cB3p : oB3p;
-        float B2p = (q >= 2) ? cB2p : oB2p;
-        float B1p = (q >= 1) ? cB1p : oB1p;
-        float Ar = ((t3r + B2r) + B1r) + Hr;
-        float Ai = ((t3i + B2i) + B1i) + Hi;
-        float P  = (((pTp + B3p) + B2p) + B1p) + Hp;     // tail of block m-4: same lane, previous tile
-        float m2 = fma_(Ai, Ai, Ar * Ar);
-        float tp = thr * P;
-        bool above = (m2 > tp * tp) && (n < n_samp);
-        uint64_t mask = __ballot(above);
-        uint64_t hit = mask;
-        for (int j = 1; j <= min_plateau; j++) hit &= (mask << j) | (prev_mask >> (64 - j));
+        float Ar, Ai;
+        uint64_t mask = detect_tile(x, n_samp, n0, thr, lane, ps, Ar, Ai);
+        uint64_t hit = plateau_hits(mask, prev_mask, min_plateau);
         if (hit) {
             int l = __builtin_ctzll(hit);
             A_t = { bcast(Ar, l), bcast(Ai, l) };
             return (int)(n0 + l);
         }
         prev_mask = mask;
-        pHr = Hr; pHi = Hi; pHp = Hp; pTr = Tr; pTi = Ti; pTp = Tp;
     }
     return -1;
 }
@@ -263,6 +285,7 @@ __device__ __forceinline__ void frame_body(const float2* __restrict__ x, long n_
 
     const LaneConst K = lane_const(lane);
     bool alive = (L >= WIFIRX_SYNC_LENGTH + 63);
+    if (!alive) fr.flags |= WIFIRX_F_TRUNCATED;
     int   fs = 0;
     float cfo_f = 0.0f;
 
@@ -373,8 +396,7 @@ __device__ __forceinline__ void frame_body(const float2* __restrict__ x, long n_
 
         for (int s = 0; s <= n_sym + 2; s++) {
             long off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
-            if (off0 + 64 > L) break;
-            if (s > 2 && (s - 3) >= (int)prm.max_sym) break;
+            if (off0 + 64 > L || (s > 2 && (s - 3) >= (int)prm.max_sym)) { fr.flags |= WIFIRX_F_TRUNCATED; break; }
             long m = off0 + lane;
             c32 xs = load_sample(x, t - 16 + m, n_samp);
             float s1, c1, s2, c2;
@@ -542,6 +564,56 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
                carrier ? carrier + slot * idx_stride : nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------
+// stream mode (the GNU Radio block's work()): detection over a span of the stream buffer.
+// Every wave owns WR_STREAM_SPAN tiles; it first replays the tile in front of its span to get the
+// block sums that tile hands over (tile -1 of the buffer is the all-zero past of the stream start).
+__global__ __launch_bounds__(256)
+void stream_detect_kernel(const float2* __restrict__ x, long n_samp, long tile0, long n_tiles, float thr,
+                          uint64_t* __restrict__ masks, float2* __restrict__ A)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long first = tile0 + wave * WR_STREAM_SPAN;
+    if (first >= tile0 + n_tiles) return;
+    long last = first + WR_STREAM_SPAN;
+    if (last > tile0 + n_tiles) last = tile0 + n_tiles;
+    DetectState ps = detect_state_zero();
+    float Ar, Ai;
+    if (first > 0) (void)detect_tile(x, n_samp, (first - 1) * 64, thr, lane, ps, Ar, Ai);
+    for (long tl = first; tl < last; tl++) {
+        uint64_t mask = detect_tile(x, n_samp, tl * 64, thr, lane, ps, Ar, Ai);
+        long n = tl * 64 + lane;
+        if (n < n_samp) A[n] = make_float2(Ar, Ai);
+        if (lane == 0) masks[tl] = mask;
+    }
+}
+
+// one wave per selected trigger of the stream
+__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK)
+void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const StreamTrig* __restrict__ trig,
+                         uint32_t n_trig, DemodParams prm, const float2* __restrict__ A,
+                         wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
+                         float* __restrict__ llr, float2* __restrict__ carrier)
+{
+    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_YLDS_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.x * WR_WAVES_PER_BLOCK + wave;
+    if (k >= n_trig) return;
+    const StreamTrig tg = trig[k];
+    float cfo_c = tg.cfo;                 // carried over from an earlier push of the same stream
+    if (!tg.pad) {
+        const float2 At = A[tg.pos];
+        cfo_c = sp_atan2(At.y, At.x) / 16.0f;
+    }
+    const size_t idx_stride = (size_t)prm.max_sym * 48;
+    frame_body(x, n_samp, tg.pos, cfo_c, tg.usable, prm, lds[wave], lane, frames + k,
+               idx ? idx + k * idx_stride : nullptr,
+               llr ? llr + k * idx_stride * prm.llr_bits : nullptr,
+               carrier ? carrier + k * idx_stride : nullptr);
+}
+
 }  // namespace wr
 
 extern "C" hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot_len,
@@ -551,5 +623,25 @@ extern "C" hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, ui
     if (n_slots == 0) return hipSuccess;
     dim3 grid((n_slots + WR_WAVES_PER_BLOCK - 1) / WR_WAVES_PER_BLOCK), block(64 * WR_WAVES_PER_BLOCK);
     hipLaunchKernelGGL(wr::demod_batch_kernel, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_samp, int64_t tile0,
+                                              int64_t n_tiles, float thr, uint64_t* masks, float2* A)
+{
+    if (n_tiles <= 0) return hipSuccess;
+    int64_t waves = (n_tiles + WR_STREAM_SPAN - 1) / WR_STREAM_SPAN;
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    hipLaunchKernelGGL(wr::stream_detect_kernel, grid, block, 0, st, x, (long)n_samp, (long)tile0, (long)n_tiles, thr, masks, A);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
+                                             uint32_t n_trig, const wr::DemodParams* prm, const float2* A,
+                                             wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier)
+{
+    if (n_trig == 0) return hipSuccess;
+    dim3 grid((n_trig + WR_WAVES_PER_BLOCK - 1) / WR_WAVES_PER_BLOCK), block(64 * WR_WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(wr::demod_stream_kernel, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier);
     return hipGetLastError();
 }

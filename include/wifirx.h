@@ -69,6 +69,8 @@ extern "C" {
 #define WIFIRX_F_LLR        0x10u   /* LLRs written for this frame (n_bpsc <= llr_bits) */
 #define WIFIRX_F_DECODED    0x20u   /* decode_mac ran (Viterbi + descramble) */
 #define WIFIRX_F_CRC_OK     0x40u   /* FCS good: PSDU delivered */
+#define WIFIRX_F_TRUNCATED  0x80u   /* demodulation stopped because the samples of this trigger (or the
+                                       output capacity max_sym) ran out, not because sync/SIGNAL failed */
 
 /* One record per slot (batch mode) or per detected frame (stream mode): the stream tags
  * `wifi_start` of sync_short / sync_long / frame_equalizer rolled into one. */

@@ -529,7 +529,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     fr->cfo_fine = 0;
     fr->snr_db = 0;
     fr->psdu_len = 0; fr->encoding = 0; fr->n_bpsc = 0; fr->n_sym = 0; fr->n_sym_out = 0;
-    if (L < WIFIRX_SYNC_LENGTH + 63) return;          /* not enough samples for the LTS search */
+    if (L < WIFIRX_SYNC_LENGTH + 63) { fr->flags |= WIFIRX_F_TRUNCATED; return; }  /* not enough samples for the LTS search */
 
     /* -- sync_short COPY: coarse derotation of the first 383 samples -- */
     c32 y[WIFIRX_SYNC_LENGTH + 63];
@@ -624,8 +624,10 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
 
     for (int s = 0; s <= n_sym + 2; s++) {
         long off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
-        if (off0 + 64 > L) break;                     /* symbol not fully inside this trigger's samples */
-        if (s > 2 && (s - 3) >= prm->max_sym) break;  /* output capacity */
+        if (off0 + 64 > L || (s > 2 && (s - 3) >= prm->max_sym)) {   /* samples / output capacity ran out */
+            fr->flags |= WIFIRX_F_TRUNCATED;
+            break;
+        }
         /* sync_short copy + sync_long copy: two derotations per sample */
         c32 z[64], X[64];
         for (int i = 0; i < 64; i++) {

@@ -1,0 +1,101 @@
+"""Stream mode (wifirx_push / wifirx_poll and the wifi_phy_rx block) against the oracle's stream driver."""
+import numpy as np
+import pytest
+
+from wifirx import txgen
+
+pytestmark = pytest.mark.gpu
+
+
+def build_stream(seed=3, noise=True):
+    """A stream like the one IRS_user sends (frames with 100 front / 1000 tail padding,
+    gnu_radio/IRS_user.py:193), mixed rates and lengths, per-frame CFO, unit-variance noise."""
+    rng = np.random.default_rng(seed)
+    parts, psdus = [], []
+    specs = [(0, 60), (2, 294), (4, 500), (7, 1000), (2, 294), (5, 120), (3, 294), (6, 64), (1, 200), (2, 294)]
+    for k, (enc, plen) in enumerate(specs):
+        psdu = txgen.make_psdus(1, plen, seed=seed * 100 + k, seq0=k)
+        tx = txgen.encode_psdus(psdu, enc, seeds=[(k % 127) + 1])
+        n = tx.samples.shape[1]
+        cfo = rng.uniform(-0.03, 0.03)
+        sig = tx.samples[0] * np.exp(1j * cfo * np.arange(n)) * np.sqrt(10 ** (24 / 10))
+        gap_front, gap_tail = 100, (1000 if k != 4 else 200)
+        parts += [np.zeros(gap_front, np.complex64), sig.astype(np.complex64), np.zeros(gap_tail, np.complex64)]
+        psdus.append(psdu[0])
+    x = np.concatenate(parts)
+    if noise:
+        x = x + ((rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size)) * np.sqrt(0.5)).astype(np.complex64)
+    return x.astype(np.complex64), psdus
+
+
+def oracle_stream(orc, x, max_sym=511):
+    prm = orc.make_params(max_sym=max_sym)
+    o = orc.demod_stream(x, prm, want_eq=True, cap=256)
+    psdu = orc.decode_batch(o["frames"], o["idx"], prm, psdu_stride=2048)
+    return o, psdu
+
+
+@pytest.mark.parametrize("chunk", [777, 4096, 100000, 10**7])
+@pytest.mark.parametrize("noise", [True, False])
+def test_push_poll_matches_oracle_stream(orc, chunk, noise):
+    from wifirx import capi
+    x, psdus = build_stream(noise=noise)
+    o, opsdu = oracle_stream(orc, x)
+    rx = capi.WifiRx(max_sym=511, want_carrier=True)
+    got = []
+    for p in range(0, x.size, chunk):
+        rx.push(x[p:p + chunk])
+        got.append(rx.poll(cap=64, want_idx=True))
+    rx._check(capi.lib().wifirx_push(rx._h, None, 0, 0))       # flush
+    got.append(rx.poll(cap=64, want_idx=True))
+    frames = np.concatenate([g["frames"] for g in got])
+    psdu = np.concatenate([g["psdu"] for g in got])
+    idx = np.concatenate([g["idx"] for g in got])
+    car = np.concatenate([g["carrier"] for g in got])
+    assert len(frames) == len(o["frames"])
+    assert np.array_equal(frames, o["frames"]), (frames, o["frames"])
+    for k in range(len(frames)):
+        n = int(frames[k]["n_sym_out"])
+        assert np.array_equal(idx[k, :n], o["idx"][k, :n])
+        assert np.array_equal(car[k, :n], o["eq"][k, :n])
+        if frames[k]["flags"] & capi.F_CRC_OK:
+            L = int(frames[k]["psdu_len"])
+            assert np.array_equal(psdu[k, :L], opsdu[k, :L])
+    ok = frames[(frames["flags"] & capi.F_CRC_OK) != 0]
+    assert len(ok) == len(psdus)          # every transmitted frame is recovered
+    rx.close()
+
+
+def test_block_publishes_reference_pdus(orc):
+    """The GNU-Radio-shaped block: PDU shape and metadata the reference's consumers rely on."""
+    from wifirx import block, grshim, app
+    x, psdus = build_stream(seed=5)
+    got_mac, got_car, got_pics = [], [], []
+
+    class Sink(grshim.basic_block):
+        def __init__(self):
+            grshim.basic_block.__init__(self, name="sink")
+            self.message_port_register_in("in")
+            self.message_port_register_in("car")
+            self.set_msg_handler("in", got_mac.append)
+            self.set_msg_handler("car", got_car.append)
+
+    rx = block.wifi_phy_rx(bandwidth=20e6, frequency=5.89e9, sensitivity=0.56, chan_est=block.LS)
+    sink = Sink()
+    pics = app.extract_pics(sink=got_pics.append)
+    grshim.msg_connect(rx, "mac_out", sink, "in")
+    grshim.msg_connect(rx, "carrier", sink, "car")
+    grshim.msg_connect(rx, "mac_out", pics, "MAC")
+    n = grshim.run_stream(rx, x, chunk=8192)
+    assert n == x.size
+    assert len(got_mac) == len(psdus)
+    for (meta, blob), ref in zip(got_mac, psdus):
+        assert blob.dtype == np.uint8 and np.array_equal(blob, ref[:-4])     # MAC frame without FCS
+        assert set(meta) >= {"frame_bytes", "encoding", "snr", "freq", "freq_offset", "dlt"}
+        assert meta["frame_bytes"] == len(ref) and 15 < meta["snr"] < 35
+    assert [len(p) for p in got_pics] == [len(r) - 32 for r in psdus]        # [24:][4:] of the blob
+    n_sym_total = sum(txgen.n_sym_for(len(r), e) for r, e in zip(psdus, [0, 2, 4, 7, 2, 5, 3, 6, 1, 2]))
+    assert len(got_car) >= n_sym_total and got_car[0][0] == {} and got_car[0][1].shape == (48,)
+    rx.set_frequency(2.6e9); rx.set_bandwidth(10e6); rx.set_sensitivity(0.6)
+    with pytest.raises(Exception):
+        rx.set_chan_est(block.LMS)
