@@ -75,6 +75,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from wifirx import capi, txgen
+    from wifirx import dist as wdist
 
     n_frames = args.frames
     n_sym = txgen.n_sym_for(PSDU_LEN, ENCODING)
@@ -101,11 +102,6 @@ def main():
     psdu_t = torch.zeros((n_frames, psdu_stride), dtype=torch.uint8, device="cuda") if do_decode else None
     out = capi.Out(frames_t.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), None,
                    psdu_t.data_ptr() if do_decode else None, psdu_stride if do_decode else 0, 1)
-    dev = dict(_raw=out)
-
-    class _Raw:
-        pass
-
     def step():
         """one pass of the hot path; returns the demod kernel's HIP-event time in ms"""
         ms = capi.C.c_float(0)
@@ -115,10 +111,7 @@ def main():
             rx._check(capi.lib().wifirx_decode_batch(rx._h, n_frames, capi.C.byref(out)))
             rx.sync()
             if world > 1:
-                gathered_psdu = [torch.empty_like(psdu_t) for _ in range(world)]
-                gathered_fr = [torch.empty_like(frames_t) for _ in range(world)]
-                dist.all_gather(gathered_psdu, psdu_t)
-                dist.all_gather(gathered_fr, frames_t)
+                wdist.all_gather_pdus(psdu_t, frames_t)
         return ms.value
 
     def barrier():

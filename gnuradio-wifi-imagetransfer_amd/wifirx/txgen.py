@@ -306,12 +306,13 @@ def impair(frames: np.ndarray, snr_db: float | None, cfo: np.ndarray | float = 0
     idx = np.arange(n)
     x = x * np.exp(1j * cfo[:, None] * idx[None, :])
     slot = np.zeros((F, total), dtype=np.complex128)
+    m = max(0, min(n, total - lead))                 # a frame longer than the slot is cut off
     if snr_db is None:
-        slot[:, lead:lead + n] = x
+        slot[:, lead:lead + m] = x[:, :m]
         return slot.astype(np.complex64)
     rng = np.random.Generator(np.random.PCG64(seed))
     g = math.sqrt(10.0 ** (snr_db / 10.0))
     noise = (rng.standard_normal((F, total)) + 1j * rng.standard_normal((F, total))) * math.sqrt(0.5)
     slot[:] = noise
-    slot[:, lead:lead + n] += g * x
+    slot[:, lead:lead + m] += g * x[:, :m]
     return slot.astype(np.complex64)
