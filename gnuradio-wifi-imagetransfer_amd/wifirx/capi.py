@@ -213,6 +213,9 @@ class WifiRx:
         d["llr"] = self.alloc(n_slots * ms * 48 * self.cfg.llr_bits * 4) if self.cfg.llr_bits else None
         d["carrier"] = self.alloc(n_slots * ms * 48 * 8) if self.cfg.want_carrier else None
         d["psdu"] = self.alloc(n_slots * psdu_stride) if psdu_stride else None
+        for k in ("frames", "idx", "llr", "carrier", "psdu"):      # the kernels only write what a frame fills
+            if d[k] is not None and d[k].nbytes:
+                d[k].upload(np.zeros(d[k].nbytes, dtype=np.uint8))
         return d
 
     def free_out(self, dev):
