@@ -21,165 +21,9 @@
 #include "wifirx.h"
 #include "wr_device.h"
 #include "wr_kernels.h"
+#include "wr_quad.h"
 
 namespace wr {
-
-// per-lane constants that do not depend on the frame
-struct LaneConst {
-    c32   tw1, tw2;     // FFT twiddles of stage 1 and 2 for the output this lane computes
-    int   src_shift;    // lane that holds, after the 3 stages, the bin this lane wants (fftshift)
-    int   carrier;      // data carrier number 0..47 of bin `lane`, -1 for pilots / DC / guards
-    float lts;          // L_i of the long training symbol (+-1, 0)
-    bool  used;         // one of the 52 occupied bins
-};
-
-__device__ __forceinline__ LaneConst lane_const(int lane)
-{
-    LaneConst k;
-    {
-        int n = lane & 15, q = lane >> 4;
-        int e = (q * n) & 63;
-        k.tw1 = { WR_TWIDDLE64[2 * e], WR_TWIDDLE64[2 * e + 1] };
-    }
-    {
-        int n = lane & 3, q = (lane >> 2) & 3;
-        int e = (q * n * 4) & 63;
-        k.tw2 = { WR_TWIDDLE64[2 * e], WR_TWIDDLE64[2 * e + 1] };
-    }
-    {
-        int kk = (lane + 32) & 63;                    // sub-carrier index (0..63) wanted by this lane
-        k.src_shift = 16 * (kk & 3) + 4 * ((kk >> 2) & 3) + (kk >> 4);
-    }
-    int i = lane;
-    bool data = (i >= 6 && i <= 58 && i != 11 && i != 25 && i != 32 && i != 39 && i != 53);
-    k.carrier = data ? (i - 6 - (i > 11) - (i > 25) - (i > 32) - (i > 39) - (i > 53)) : -1;
-    k.lts = WR_LTS_FREQ[i];
-    k.used = (i >= 6 && i <= 58 && i != 32);
-    return k;
-}
-
-// radix-4 DIF butterfly output q of inputs x0..x3 (spec section 4.3)
-__device__ __forceinline__ c32 bfly4(c32 x0, c32 x1, c32 x2, c32 x3, int q)
-{
-    bool odd = q & 1;
-    c32 x2s = odd ? cneg(x2) : x2;
-    c32 x3s = odd ? cneg(x3) : x3;
-    c32 tac = cadd(x0, x2s);          // q even: x0+x2, q odd: x0-x2
-    c32 tbd = cadd(x1, x3s);          // q even: x1+x3, q odd: x1-x3
-    c32 u;
-    if (q == 0)      u = tbd;
-    else if (q == 2) u = cneg(tbd);
-    else if (q == 1) u = { tbd.im, -tbd.re };    // -j * tbd
-    else             u = { -tbd.im, tbd.re };    // +j * tbd
-    return cadd(tac, u);
-}
-
-// 64-point forward DFT of one value per lane, output bin i (sub-carrier i-32) on lane i
-__device__ __forceinline__ c32 fft64_wave(c32 v, int lane, const LaneConst& k)
-{
-    {   // stage 1: span 16
-        int n = lane & 15, q = lane >> 4;
-        c32 x0 = shfl(v, n), x1 = shfl(v, n + 16), x2 = shfl(v, n + 32), x3 = shfl(v, n + 48);
-        v = sp_cmul(bfly4(x0, x1, x2, x3, q), k.tw1);
-    }
-    {   // stage 2: span 4 inside blocks of 16
-        int base = lane & 48, n = lane & 3, q = (lane >> 2) & 3;
-        c32 x0 = shfl(v, base + n), x1 = shfl(v, base + n + 4), x2 = shfl(v, base + n + 8),
-            x3 = shfl(v, base + n + 12);
-        v = sp_cmul(bfly4(x0, x1, x2, x3, q), k.tw2);
-    }
-    {   // stage 3: span 1 inside blocks of 4 (twiddle 1: the spec's multiply by (1,0) is exact)
-        int base = lane & 60, q = lane & 3;
-        c32 x0 = shfl(v, base), x1 = shfl(v, base + 1), x2 = shfl(v, base + 2), x3 = shfl(v, base + 3);
-        v = bfly4(x0, x1, x2, x3, q);
-    }
-    return shfl(v, k.src_shift);
-}
-
-__device__ __forceinline__ c32 load_sample(const float2* __restrict__ x, long n, long n_samp)
-{
-    c32 z = { 0.0f, 0.0f };
-    if (n >= 0 && n < n_samp) {
-        float2 t = x[n];
-        z.re = t.x;
-        z.im = t.y;
-    }
-    return z;
-}
-
-__device__ __forceinline__ uint8_t decide(c32 y, int n_bpsc)
-{
-    float re = y.re, im = y.im, are = __builtin_fabsf(re), aim = __builtin_fabsf(im);
-    unsigned r;
-    if (n_bpsc == 1) {
-        r = re > 0.0f;
-    } else if (n_bpsc == 2) {
-        r = (re > 0.0f) | ((im > 0.0f) << 1);
-    } else if (n_bpsc == 4) {
-        r = (re > 0.0f) | ((are < WR_T16_2) << 1) | ((im > 0.0f) << 2) | ((aim < WR_T16_2) << 3);
-    } else {
-        r = (re > 0.0f) | ((are < WR_T64_4) << 1) | (((are < WR_T64_6) && (are > WR_T64_2)) << 2) |
-            ((im > 0.0f) << 3) | ((aim < WR_T64_4) << 4) | (((aim < WR_T64_6) && (aim > WR_T64_2)) << 5);
-    }
-    return (uint8_t)r;
-}
-
-// Viterbi over the 24 SIGNAL bits, lane <-> state.  cbits: the 48 de-interleaved hard decisions
-// (bit j = coded bit j).  Returns the 24 decoded bits (bit t = decoded bit t), wave-uniform.
-__device__ __forceinline__ uint32_t viterbi_signal(uint64_t cbits, int lane)
-{
-    const int s = lane, u = s & 1, p0 = s >> 1, p1 = (s >> 1) | 32;
-    const int f0 = (p0 << 1) | u, f1 = (p1 << 1) | u;
-    const int a0 = __builtin_popcount(f0 & 0155) & 1, b0 = __builtin_popcount(f0 & 0117) & 1;
-    const int a1 = __builtin_popcount(f1 & 0155) & 1, b1 = __builtin_popcount(f1 & 0117) & 1;
-    int pm = (s == 0) ? 0 : (1 << 28);
-    uint64_t dec[24];
-#pragma unroll
-    for (int t = 0; t < 24; t++) {
-        int ra = (int)((cbits >> (2 * t)) & 1), rb = (int)((cbits >> (2 * t + 1)) & 1);
-        int m0 = __shfl(pm, p0, 64) + (ra != a0) + (rb != b0);
-        int m1 = __shfl(pm, p1, 64) + (ra != a1) + (rb != b1);
-        bool sel = m1 < m0;
-        pm = sel ? m1 : m0;
-        dec[t] = __ballot(sel);
-    }
-    // best final state: smallest metric, lowest index on ties
-    int key = (pm << 6) | s;      // pm < 2^28/… : metrics stay far below 2^25 here
-#pragma unroll
-    for (int k = 1; k < 64; k <<= 1) {
-        int o = __shfl_xor(key, k, 64);
-        key = o < key ? o : key;
-    }
-    int st = key & 63;
-    uint32_t bits = 0;
-#pragma unroll
-    for (int t = 23; t >= 0; t--) {
-        bits |= (uint32_t)(st & 1) << t;
-        int h = (int)((dec[t] >> st) & 1);
-        st = (st >> 1) | (h << 5);
-    }
-    return bits;
-}
-
-__device__ __forceinline__ bool parse_signal(uint32_t bits, int& enc, int& len)
-{
-    int par = __builtin_popcount(bits & 0x1ffff) & 1;
-    if (par != (int)((bits >> 17) & 1)) return false;
-    int r = bits & 15;
-    len = (bits >> 5) & 0xfff;
-    switch (r) {
-    case 11: enc = 0; break;
-    case 15: enc = 1; break;
-    case 10: enc = 2; break;
-    case 14: enc = 3; break;
-    case 9:  enc = 4; break;
-    case 13: enc = 5; break;
-    case 8:  enc = 6; break;
-    case 12: enc = 7; break;
-    default: return false;
-    }
-    return true;
-}
 
 // ---------------------------------------------------------------------------------------------
 // detect phase (a1 + a2).  One tile = 64 consecutive samples, lane <-> sample; the window sums
@@ -266,302 +110,57 @@ __device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n
 }
 
 // ---------------------------------------------------------------------------------------------
-// Everything after the trigger, for one frame owned by this wave.
-//   x: slot / stream base, n_samp: its length, t: trigger, cfo_c: coarse CFO, L: usable copied samples
-//   ylds: wave-private LDS scratch of WR_YLDS_FLOATS floats
-__device__ __forceinline__ void frame_body(const float2* __restrict__ x, long n_samp, long t, float cfo_c,
-                                           long L, const DemodParams& prm, float* ylds, int lane,
-                                           wifirx_frame* fr_out, uint8_t* __restrict__ idx,
-                                           float* __restrict__ llr, float2* __restrict__ carrier)
+// batch kernel: one wave = 4 consecutive slots, WR_WAVES_PER_BLOCK waves per workgroup.
+// Preamble phase per slot with the whole wave (lane = sample / lag), then the four frames walk their
+// symbols together (wr_quad.h).
+__device__ __forceinline__ FrameSeed seed_none()
 {
-    wifirx_frame fr;
-    fr.flags = WIFIRX_F_DETECTED;
-    fr.trigger = (int32_t)t;
-    fr.frame_start = 0;
-    fr.cfo_coarse = cfo_c;
-    fr.cfo_fine = 0.0f;
-    fr.snr_db = 0.0f;
-    fr.psdu_len = 0; fr.encoding = 0; fr.n_bpsc = 0; fr.n_sym = 0; fr.n_sym_out = 0;
-
-    const LaneConst K = lane_const(lane);
-    bool alive = (L >= WIFIRX_SYNC_LENGTH + 63);
-    if (!alive) fr.flags |= WIFIRX_F_TRUNCATED;
-    int   fs = 0;
-    float cfo_f = 0.0f;
-
-    if (alive) {
-        // -- sync_short copy of the first 383 samples into LDS (6 x 64 >= 383) --
-#pragma unroll
-        for (int pass = 0; pass < 6; pass++) {
-            int m = pass * 64 + lane;
-            c32 xs = load_sample(x, t - 16 + m, n_samp);
-            float s, c;
-            sp_sincos(-cfo_c * (float)m, s, c);
-            c32 y = sp_rot(xs, s, c);
-            ylds[2 * m] = y.re;
-            ylds[2 * m + 1] = y.im;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // -- sync_long: 64-tap LTS correlation over 320 lags, lane <-> lag --
-        c32   corr[5];
-        float mag[5];
-#pragma unroll
-        for (int pass = 0; pass < 5; pass++) {
-            int i = pass * 64 + lane;
-            float ar = 0.0f, ai = 0.0f;
-#pragma unroll 8
-            for (int k = 0; k < 64; k++) {
-                float lr = WR_LTS_TIME[2 * k], li = WR_LTS_TIME[2 * k + 1];
-                float yr = ylds[2 * (i + k)], yi = ylds[2 * (i + k) + 1];
-                ar = fma_(lr, yr, ar);
-                ar = fma_(li, yi, ar);
-                ai = fma_(lr, yi, ai);
-                ai = fma_(-li, yr, ai);
-            }
-            corr[pass] = { ar, ai };
-            mag[pass] = fma_(ai, ai, ar * ar);
-        }
-        // top 4 magnitudes, ties -> lower lag
-        int   top_off[4];
-        c32   top_val[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            // local best of this lane's 5 candidates (lower pass = lower lag wins ties)
-            unsigned long long key = 0;
-#pragma unroll
-            for (int pass = 0; pass < 5; pass++) {
-                int i = pass * 64 + lane;
-                unsigned long long kk = ((unsigned long long)__float_as_uint(mag[pass]) << 32) |
-                                        (unsigned)(0xffffffffu - (unsigned)i);
-                bool valid = mag[pass] >= 0.0f;
-                if (valid && kk > key) key = kk;
-            }
-#pragma unroll
-            for (int k = 1; k < 64; k <<= 1) {
-                unsigned long long o = __shfl_xor(key, k, 64);
-                key = o > key ? o : key;
-            }
-            int w = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-            int wl = w & 63, wp = w >> 6;
-            c32 val = { 0.0f, 0.0f };
-#pragma unroll
-            for (int pass = 0; pass < 5; pass++) {
-                if (pass == wp) {
-                    val = bcast(corr[pass], wl);
-                    if (lane == wl) mag[pass] = -1.0f;
-                }
-            }
-            top_off[r] = w;
-            top_val[r] = val;
-        }
-        int found = 0;
-        fs = WIFIRX_SYNC_LENGTH;
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-#pragma unroll
-            for (int k = i + 1; k < 4; k++) {
-                if (found == 64) continue;
-                int oi = top_off[i], ok = top_off[k];
-                c32 first = oi > ok ? top_val[k] : top_val[i];
-                c32 second = oi > ok ? top_val[i] : top_val[k];
-                int diff = oi > ok ? oi - ok : ok - oi;
-                if (diff == 64 || diff == 63 || diff == 65) {
-                    float pr = fma_(first.im, second.im, first.re * second.re);
-                    float pi = fma_(first.im, second.re, -(first.re * second.im));
-                    fs = oi < ok ? oi : ok;
-                    cfo_f = sp_atan2(pi, pr) / (float)diff;
-                    found = diff;
-                }
-            }
-        }
-        alive = found != 0;
-        if (alive) {
-            fr.flags |= WIFIRX_F_SYNC;
-            fr.frame_start = fs;
-            fr.cfo_fine = cfo_f;
-        }
-    }
-
-    if (alive) {
-        const double bw = prm.bandwidth, fc = prm.frequency;
-        const double two_pi = 2 * 3.14159265358979323846;
-        const double tag = (double)cfo_c - (double)cfo_f;
-        const double eps0 = tag * bw / (two_pi * fc);
-        const double er_scale = bw / (two_pi * fc * 80);
-        double d_er = 0.0;
-        c32 prev0 = { 0, 0 }, prev1 = { 0, 0 }, prev2 = { 0, 0 }, prev3 = { 0, 0 };
-        c32 H = { 0, 0 };
-        int n_sym = 0, n_bpsc = 1, n_out = 0;
-        bool have_signal = false, want_llr = false;
-
-        for (int s = 0; s <= n_sym + 2; s++) {
-            long off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
-            if (off0 + 64 > L || (s > 2 && (s - 3) >= (int)prm.max_sym)) { fr.flags |= WIFIRX_F_TRUNCATED; break; }
-            long m = off0 + lane;
-            c32 xs = load_sample(x, t - 16 + m, n_samp);
-            float s1, c1, s2, c2;
-            sp_sincos(-cfo_c * (float)m, s1, c1);
-            sp_sincos((float)m * cfo_f, s2, c2);
-            c32 X = fft64_wave(sp_rot(sp_rot(xs, s1, c1), s2, c2), lane, K);
-
-            // (1) sampling offset
-            {
-                double t4 = two_pi * s * 80 * (eps0 + d_er);
-                float ang = (float)(t4 * (double)(lane - 32) / 64);
-                float sn, cs;
-                sp_sincos(ang, sn, cs);
-                X = sp_rot(X, sn, cs);
-            }
-            // (2) pilots
-            c32 X11 = bcast(X, 11), X25 = bcast(X, 25), X39 = bcast(X, 39), X53 = bcast(X, 53);
-            bool pneg = (s >= 2) && (WR_POLARITY[(s - 2) % 127] < 0);
-            c32 S;
-            if (s < 2) S = cadd(cadd(csub(X11, X25), X39), X53);
-            else {
-                S = csub(cadd(cadd(X11, X39), X25), X53);
-                if (pneg) S = cneg(S);
-            }
-            float beta = sp_atan2(S.im, S.re);
-            // (3) residual offset estimate
-            c32 cur0, cur1, cur2, cur3;
-            if (s < 2) { cur0 = X11; cur1 = cneg(X25); cur2 = X39; cur3 = X53; }
-            else {
-                cur0 = pneg ? cneg(X11) : X11;
-                cur1 = pneg ? cneg(X25) : X25;
-                cur2 = pneg ? cneg(X39) : X39;
-                cur3 = pneg ? X53 : cneg(X53);
-            }
-            double er = 0.0;
-            if (s >= 2) {
-                c32 acc = cadd(cadd(cadd(sp_conj_mul(prev0, cur0), sp_conj_mul(prev1, cur1)),
-                                    sp_conj_mul(prev2, cur2)), sp_conj_mul(prev3, cur3));
-                er = (double)sp_atan2(acc.im, acc.re) * er_scale;
-            }
-            prev0 = cur0; prev1 = cur1; prev2 = cur2; prev3 = cur3;
-            // (4) common phase
-            {
-                float sn, cs;
-                sp_sincos(-beta, sn, cs);
-                X = sp_rot(X, sn, cs);
-            }
-            // (5) IIR
-            if (s >= 2) {
-                double alpha = 0.1;
-                d_er = (1 - alpha) * d_er + alpha * er;
-            }
-            // (6) LS equalizer
-            if (s == 0) {
-                H = X;
-            } else if (s == 1) {
-                c32 d = csub(H, X), u = cadd(H, X);
-                float nv = K.used ? fma_(d.im, d.im, d.re * d.re) : 0.0f;
-                float sv = K.used ? fma_(u.im, u.im, u.re * u.re) : 0.0f;
-                float g = 0.5f * K.lts;
-                if (K.used) { H.re = u.re * g; H.im = u.im * g; }
-                float signal = tree_sum64(sv), noise = tree_sum64(nv);
-                fr.snr_db = sp_snr_db(signal, noise);
-            } else {
-                int  nb = (s == 2) ? 1 : n_bpsc;
-                bool is_data = K.carrier >= 0;
-                c32  Y = { 0.0f, 0.0f };
-                if (is_data) {
-                    float d = fma_(H.im, H.im, H.re * H.re);
-                    Y.re = fma_(X.im, H.im, X.re * H.re) / d;
-                    Y.im = fma_(X.im, H.re, -(X.re * H.im)) / d;
-                }
-                uint8_t bits = decide(Y, nb);
-                if (s == 2) {
-                    // (7) SIGNAL: gather the 48 decisions in carrier order, de-interleave, Viterbi
-                    uint64_t b = __ballot(is_data && (bits & 1));
-                    uint64_t cm = ((b >> 6) & 0x1full) | (((b >> 12) & 0x1fffull) << 5) |
-                                  (((b >> 26) & 0x3full) << 18) | (((b >> 33) & 0x3full) << 24) |
-                                  (((b >> 40) & 0x1fffull) << 30) | (((b >> 54) & 0x1full) << 43);
-                    uint64_t de = 0;
-#pragma unroll
-                    for (int j = 0; j < 48; j++) de |= ((cm >> (3 * (j % 16) + j / 16)) & 1ull) << j;
-                    uint32_t sig = viterbi_signal(de, lane);
-                    int enc = 0, len = 0;
-                    if (!parse_signal(sig, enc, len)) break;
-                    const int nbpsc_tab[8] = { 1, 1, 2, 2, 4, 4, 6, 6 };
-                    const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
-                    have_signal = true;
-                    n_bpsc = nbpsc_tab[enc];
-                    int nd = ndbps_tab[enc];
-                    n_sym = (16 + 8 * len + 6 + nd - 1) / nd;
-                    fr.flags |= WIFIRX_F_SIGNAL;
-                    fr.psdu_len = (uint16_t)len;
-                    fr.encoding = (uint8_t)enc;
-                    fr.n_bpsc = (uint8_t)n_bpsc;
-                    fr.n_sym = (uint16_t)n_sym;
-                    want_llr = (llr != nullptr) && ((int)prm.llr_bits >= n_bpsc);
-                    if (want_llr) fr.flags |= WIFIRX_F_LLR;
-                } else {
-                    // (8) data symbol q
-                    int q = s - 3;
-                    if (is_data) {
-                        size_t o = (size_t)q * 48 + K.carrier;
-                        if (idx) idx[o] = bits;
-                        if (carrier) carrier[o] = make_float2(Y.re, Y.im);
-                        if (want_llr) {
-                            float are = __builtin_fabsf(Y.re), aim = __builtin_fabsf(Y.im);
-                            float* lp = llr + o * n_bpsc;
-                            if (n_bpsc == 1) {
-                                lp[0] = Y.re;
-                            } else if (n_bpsc == 2) {
-                                *reinterpret_cast<float2*>(lp) = make_float2(Y.re, Y.im);
-                            } else if (n_bpsc == 4) {
-                                *reinterpret_cast<float4*>(lp) = make_float4(Y.re, WR_T16_2 - are, Y.im, WR_T16_2 - aim);
-                            } else {
-                                float2* l2 = reinterpret_cast<float2*>(lp);
-                                l2[0] = make_float2(Y.re, WR_T64_4 - are);
-                                l2[1] = make_float2(WR_T64_2 - __builtin_fabsf(are - WR_T64_4), Y.im);
-                                l2[2] = make_float2(WR_T64_4 - aim, WR_T64_2 - __builtin_fabsf(aim - WR_T64_4));
-                            }
-                        }
-                    }
-                    n_out = q + 1;
-                }
-            }
-        }
-        fr.n_sym_out = (uint16_t)n_out;
-        if (have_signal && n_out == n_sym) fr.flags |= WIFIRX_F_COMPLETE;
-    }
-    if (lane == 0) *fr_out = fr;
+    FrameSeed sd;
+    sd.x = nullptr; sd.n_samp = 0; sd.t = -1; sd.L = 0; sd.cfo_c = 0.0f; sd.cfo_f = 0.0f; sd.fs = 0; sd.flags = 0; sd.out = -1;
+    return sd;
 }
 
-// ---------------------------------------------------------------------------------------------
-// batch kernel: one wave per slot, WR_WAVES_PER_BLOCK slots per workgroup
+// sync_short found trigger t in (x, n_samp): run the LTS search when enough samples were copied
+__device__ __forceinline__ void seed_sync(FrameSeed& sd, float* lds, int lane)
+{
+    sd.flags = WIFIRX_F_DETECTED;
+    if (sd.L < WIFIRX_SYNC_LENGTH + 63) {
+        sd.flags |= WIFIRX_F_TRUNCATED;
+        return;
+    }
+    if (preamble_sync(sd.x, sd.n_samp, sd.t, sd.cfo_c, lds, lane, sd.fs, sd.cfo_f)) sd.flags |= WIFIRX_F_SYNC;
+}
+
 __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK)
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
                         DemodParams prm, wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
                         float* __restrict__ llr, float2* __restrict__ carrier)
 {
-    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_YLDS_FLOATS];
+    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t slot = blockIdx.x * WR_WAVES_PER_BLOCK + wave;
-    if (slot >= n_slots) return;
-    const float2* x = iq + (size_t)slot * slot_len;
-    const size_t idx_stride = (size_t)prm.max_sym * 48;
-
-    c32 A_t = { 0, 0 };
-    int t = detect_first(x, slot_len, prm.threshold, prm.min_plateau, lane, A_t);
-    if (t < 0) {
-        if (lane == 0) {
-            wifirx_frame fr;
-            fr.flags = 0; fr.trigger = -1; fr.frame_start = 0; fr.cfo_coarse = 0; fr.cfo_fine = 0;
-            fr.snr_db = 0; fr.psdu_len = 0; fr.encoding = 0; fr.n_bpsc = 0; fr.n_sym = 0; fr.n_sym_out = 0;
-            frames[slot] = fr;
-        }
-        return;
+    const uint32_t slot0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;
+    if (slot0 >= n_slots) return;
+    FrameSeed seed[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        seed[f] = seed_none();
+        const uint32_t slot = slot0 + f;
+        if (slot >= n_slots) continue;
+        FrameSeed& sd = seed[f];
+        sd.x = iq + (size_t)slot * slot_len;
+        sd.n_samp = slot_len;
+        sd.out = slot;
+        c32 A_t = { 0, 0 };
+        int t = detect_first(sd.x, slot_len, prm.threshold, prm.min_plateau, lane, A_t);
+        sd.t = t;
+        if (t < 0) continue;
+        sd.cfo_c = sp_atan2(A_t.im, A_t.re) / 16.0f;
+        long L = (long)slot_len - (t - 16);
+        sd.L = L > WIFIRX_MAX_SAMPLES ? WIFIRX_MAX_SAMPLES : L;
+        seed_sync(sd, lds[wave], lane);
     }
-    float cfo_c = sp_atan2(A_t.im, A_t.re) / 16.0f;
-    long L = (long)slot_len - (t - 16);
-    if (L > WIFIRX_MAX_SAMPLES) L = WIFIRX_MAX_SAMPLES;
-    frame_body(x, slot_len, t, cfo_c, L, prm, lds[wave], lane, frames + slot,
-               idx ? idx + slot * idx_stride : nullptr,
-               llr ? llr + slot * idx_stride * prm.llr_bits : nullptr,
-               carrier ? carrier + slot * idx_stride : nullptr);
+    frames_quad(seed, prm, lds[wave], lane, frames, idx, llr, carrier);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -589,29 +188,39 @@ void stream_detect_kernel(const float2* __restrict__ x, long n_samp, long tile0,
     }
 }
 
-// one wave per selected trigger of the stream
+// one wave per four selected triggers of the stream
 __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK)
 void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const StreamTrig* __restrict__ trig,
                          uint32_t n_trig, DemodParams prm, const float2* __restrict__ A,
                          wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
                          float* __restrict__ llr, float2* __restrict__ carrier)
 {
-    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_YLDS_FLOATS];
+    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * WR_WAVES_PER_BLOCK + wave;
-    if (k >= n_trig) return;
-    const StreamTrig tg = trig[k];
-    float cfo_c = tg.cfo;                 // carried over from an earlier push of the same stream
-    if (!tg.pad) {
-        const float2 At = A[tg.pos];
-        cfo_c = sp_atan2(At.y, At.x) / 16.0f;
+    const uint32_t k0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;
+    if (k0 >= n_trig) return;
+    FrameSeed seed[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        seed[f] = seed_none();
+        const uint32_t k = k0 + f;
+        if (k >= n_trig) continue;
+        const StreamTrig tg = trig[k];
+        FrameSeed& sd = seed[f];
+        sd.x = x;
+        sd.n_samp = n_samp;
+        sd.out = k;
+        sd.t = tg.pos;
+        sd.L = tg.usable;
+        sd.cfo_c = tg.cfo;                 // carried over from an earlier push of the same stream
+        if (!tg.pad) {
+            const float2 At = A[tg.pos];
+            sd.cfo_c = sp_atan2(At.y, At.x) / 16.0f;
+        }
+        seed_sync(sd, lds[wave], lane);
     }
-    const size_t idx_stride = (size_t)prm.max_sym * 48;
-    frame_body(x, n_samp, tg.pos, cfo_c, tg.usable, prm, lds[wave], lane, frames + k,
-               idx ? idx + k * idx_stride : nullptr,
-               llr ? llr + k * idx_stride * prm.llr_bits : nullptr,
-               carrier ? carrier + k * idx_stride : nullptr);
+    frames_quad(seed, prm, lds[wave], lane, frames, idx, llr, carrier);
 }
 
 }  // namespace wr
@@ -621,7 +230,7 @@ extern "C" hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, ui
                                             wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier)
 {
     if (n_slots == 0) return hipSuccess;
-    dim3 grid((n_slots + WR_WAVES_PER_BLOCK - 1) / WR_WAVES_PER_BLOCK), block(64 * WR_WAVES_PER_BLOCK);
+    dim3 grid((n_slots + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
     hipLaunchKernelGGL(wr::demod_batch_kernel, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier);
     return hipGetLastError();
 }
@@ -641,7 +250,7 @@ extern "C" hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, in
                                              wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier)
 {
     if (n_trig == 0) return hipSuccess;
-    dim3 grid((n_trig + WR_WAVES_PER_BLOCK - 1) / WR_WAVES_PER_BLOCK), block(64 * WR_WAVES_PER_BLOCK);
+    dim3 grid((n_trig + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
     hipLaunchKernelGGL(wr::demod_stream_kernel, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier);
     return hipGetLastError();
 }

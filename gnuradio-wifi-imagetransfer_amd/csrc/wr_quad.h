@@ -1,0 +1,523 @@
+// wr_quad.h -- the per-frame part of the chain, four frames per wavefront.
+//
+// Layout: row f = lanes 16f..16f+15 owns frame f of the wave; lane r of a row holds the four
+// sub-carriers i = r + 16 j (j = 0..3) of the current OFDM symbol.  The four frames walk their
+// symbols in lock step, so
+//   * the per-frame scalar chain of frame_equalizer (pilot phase, residual-offset IIR, two atan2, the
+//     double-precision sampling-offset factor) is computed once per row, i.e. for 4 frames per
+//     instruction instead of 1;
+//   * the radix-4 FFT runs in registers: stage k of a lane is one 4-point butterfly; between stages the
+//     64 values of a row are transposed through 512 B of wave-private LDS;
+//   * pilots reach every lane of their row by DPP row broadcast, not through the LDS crossbar.
+// The preamble work (short-preamble scan, 64-tap LTS correlation over 320 lags) keeps lane <-> sample /
+// lag and is done for the four frames one after the other by the whole wave.
+//
+// Arithmetic is the numerics spec of DESIGN.md section 4, value for value: only the lane that computes a value
+// changed with respect to the one-frame-per-wave version, so outputs stay bit-identical to the oracle.
+#pragma once
+#include "wr_device.h"
+#include "wr_kernels.h"
+
+namespace wr {
+
+#define WR_QLDS_FLOATS 768          // per wave: max(383 preamble samples, 4 rows x 64 values) complex
+
+__device__ __forceinline__ c32 load_sample(const float2* __restrict__ x, long n, long n_samp)
+{
+    c32 z = { 0.0f, 0.0f };
+    if (n >= 0 && n < n_samp) {
+        float2 t = x[n];
+        z.re = t.x;
+        z.im = t.y;
+    }
+    return z;
+}
+
+__device__ __forceinline__ uint8_t decide(c32 y, int n_bpsc)
+{
+    float re = y.re, im = y.im, are = __builtin_fabsf(re), aim = __builtin_fabsf(im);
+    unsigned r;
+    if (n_bpsc == 1) {
+        r = re > 0.0f;
+    } else if (n_bpsc == 2) {
+        r = (re > 0.0f) | ((im > 0.0f) << 1);
+    } else if (n_bpsc == 4) {
+        r = (re > 0.0f) | ((are < WR_T16_2) << 1) | ((im > 0.0f) << 2) | ((aim < WR_T16_2) << 3);
+    } else {
+        r = (re > 0.0f) | ((are < WR_T64_4) << 1) | (((are < WR_T64_6) && (are > WR_T64_2)) << 2) |
+            ((im > 0.0f) << 3) | ((aim < WR_T64_4) << 4) | (((aim < WR_T64_6) && (aim > WR_T64_2)) << 5);
+    }
+    return (uint8_t)r;
+}
+
+// Viterbi over the 24 SIGNAL bits, lane <-> state.  cbits: the 48 de-interleaved hard decisions
+// (bit j = coded bit j).  Returns the 24 decoded bits (bit t = decoded bit t), wave-uniform.
+__device__ __forceinline__ uint32_t viterbi_signal(uint64_t cbits, int lane)
+{
+    const int s = lane, u = s & 1, p0 = s >> 1, p1 = (s >> 1) | 32;
+    const int f0 = (p0 << 1) | u, f1 = (p1 << 1) | u;
+    const int a0 = __builtin_popcount(f0 & 0155) & 1, b0 = __builtin_popcount(f0 & 0117) & 1;
+    const int a1 = __builtin_popcount(f1 & 0155) & 1, b1 = __builtin_popcount(f1 & 0117) & 1;
+    int pm = (s == 0) ? 0 : (1 << 24);
+    uint64_t dec[24];
+#pragma unroll
+    for (int t = 0; t < 24; t++) {
+        int ra = (int)((cbits >> (2 * t)) & 1), rb = (int)((cbits >> (2 * t + 1)) & 1);
+        int m0 = __shfl(pm, p0, 64) + (ra != a0) + (rb != b0);
+        int m1 = __shfl(pm, p1, 64) + (ra != a1) + (rb != b1);
+        bool sel = m1 < m0;
+        pm = sel ? m1 : m0;
+        dec[t] = __ballot(sel);
+    }
+    int key = (pm << 6) | s;      // best final state: smallest metric, lowest index on ties
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+        int o = __shfl_xor(key, k, 64);
+        key = o < key ? o : key;
+    }
+    int st = key & 63;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int t = 23; t >= 0; t--) {
+        bits |= (uint32_t)(st & 1) << t;
+        int h = (int)((dec[t] >> st) & 1);
+        st = (st >> 1) | (h << 5);
+    }
+    return bits;
+}
+
+__device__ __forceinline__ bool parse_signal(uint32_t bits, int& enc, int& len)
+{
+    int par = __builtin_popcount(bits & 0x1ffff) & 1;
+    if (par != (int)((bits >> 17) & 1)) return false;
+    int r = bits & 15;
+    len = (bits >> 5) & 0xfff;
+    switch (r) {
+    case 11: enc = 0; break;
+    case 15: enc = 1; break;
+    case 10: enc = 2; break;
+    case 14: enc = 3; break;
+    case 9:  enc = 4; break;
+    case 13: enc = 5; break;
+    case 8:  enc = 6; break;
+    case 12: enc = 7; break;
+    default: return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a2 copy + a3: sync_short's first 383 copied samples, LTS correlation, frame start, fine CFO.
+// lane <-> sample / lag; all results wave-uniform.  Returns false when no LTS pair was found.
+__device__ __forceinline__ bool preamble_sync(const float2* __restrict__ x, long n_samp, long t, float cfo_c,
+                                              float* ylds, int lane, int& fs, float& cfo_f)
+{
+#pragma unroll
+    for (int pass = 0; pass < 6; pass++) {
+        int m = pass * 64 + lane;
+        c32 xs = load_sample(x, t - 16 + m, n_samp);
+        float s, c;
+        sp_sincos(-cfo_c * (float)m, s, c);
+        c32 y = sp_rot(xs, s, c);
+        ylds[2 * m] = y.re;
+        ylds[2 * m + 1] = y.im;
+    }
+    __builtin_amdgcn_wave_barrier();
+    c32   corr[5];
+    float mag[5];
+#pragma unroll
+    for (int pass = 0; pass < 5; pass++) {
+        int i = pass * 64 + lane;
+        float ar = 0.0f, ai = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < 64; k++) {
+            float lr = WR_LTS_TIME[2 * k], li = WR_LTS_TIME[2 * k + 1];
+            float yr = ylds[2 * (i + k)], yi = ylds[2 * (i + k) + 1];
+            ar = fma_(lr, yr, ar);
+            ar = fma_(li, yi, ar);
+            ai = fma_(lr, yi, ai);
+            ai = fma_(-li, yr, ai);
+        }
+        corr[pass] = { ar, ai };
+        mag[pass] = fma_(ai, ai, ar * ar);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int top_off[4];
+    c32 top_val[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsigned long long key = 0;
+#pragma unroll
+        for (int pass = 0; pass < 5; pass++) {
+            int i = pass * 64 + lane;
+            unsigned long long kk = ((unsigned long long)__float_as_uint(mag[pass]) << 32) |
+                                    (unsigned)(0xffffffffu - (unsigned)i);
+            bool valid = mag[pass] >= 0.0f;
+            if (valid && kk > key) key = kk;
+        }
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) {
+            unsigned long long o = __shfl_xor(key, k, 64);
+            key = o > key ? o : key;
+        }
+        int w = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+        int wl = w & 63, wp = w >> 6;
+        c32 val = { 0.0f, 0.0f };
+#pragma unroll
+        for (int pass = 0; pass < 5; pass++) {
+            if (pass == wp) {
+                val = bcast(corr[pass], wl);
+                if (lane == wl) mag[pass] = -1.0f;
+            }
+        }
+        top_off[r] = w;
+        top_val[r] = val;
+    }
+    int found = 0;
+    fs = WIFIRX_SYNC_LENGTH;
+    cfo_f = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int k = i + 1; k < 4; k++) {
+            if (found == 64) continue;
+            int oi = top_off[i], ok = top_off[k];
+            c32 first = oi > ok ? top_val[k] : top_val[i];
+            c32 second = oi > ok ? top_val[i] : top_val[k];
+            int diff = oi > ok ? oi - ok : ok - oi;
+            if (diff == 64 || diff == 63 || diff == 65) {
+                float pr = fma_(first.im, second.im, first.re * second.re);
+                float pi = fma_(first.im, second.re, -(first.re * second.im));
+                fs = oi < ok ? oi : ok;
+                cfo_f = sp_atan2(pi, pr) / (float)diff;
+                found = diff;
+            }
+        }
+    }
+    return found != 0;
+}
+
+// what the preamble phase hands to the symbol phase for one frame (all wave-uniform)
+struct FrameSeed {
+    const float2* x;      // stream / slot the frame lives in
+    long     n_samp;
+    long     t;           // trigger index, -1: no frame in this row
+    long     L;           // usable copied samples
+    float    cfo_c;
+    float    cfo_f;
+    int      fs;
+    uint32_t flags;       // DETECTED [| SYNC] [| TRUNCATED]
+    long     out;         // index of the frame's record / output slices, -1: none
+};
+
+// in-register 4-point DIF butterfly (spec section 4.4)
+__device__ __forceinline__ void bfly4_reg(c32& a, c32& b, c32& c, c32& d)
+{
+    c32 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+    a = cadd(t0, t2);
+    b = { t1.re + t3.im, t1.im - t3.re };     // t1 - j t3
+    c = csub(t0, t2);
+    d = { t1.re - t3.im, t1.im + t3.re };     // t1 + j t3
+}
+
+template <int LANE>
+__device__ __forceinline__ float row_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + LANE, 0xf, 0xf, false));
+}
+template <int LANE>
+__device__ __forceinline__ c32 row_bcast(c32 v) { return { row_bcast<LANE>(v.re), row_bcast<LANE>(v.im) }; }
+
+// sum over the 16 lanes of a row in the order of the spec's xor tree (steps 1,2,4,8)
+__device__ __forceinline__ float row_xor_sum16(float v)
+{
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));  // xor 1
+    v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));  // xor 2
+    v = v + __shfl_xor(v, 4, 64);
+    v = v + __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3 copy + a4 + a5 + a6 + a7 for the four frames of a wave.
+__device__ __forceinline__ void frames_quad(const FrameSeed (&seed)[4], const DemodParams& prm, float* qlds, int lane,
+                                            wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx_all,
+                                            float* __restrict__ llr_all, float2* __restrict__ car_all)
+{
+    const int row = lane >> 4, r = lane & 15;
+    // ---- row-uniform frame state, one copy per lane ----
+    const float2* x = seed[0].x;
+    long  n_samp = seed[0].n_samp, t16 = seed[0].t - 16, L = seed[0].L, out = seed[0].out;
+    float cfo_c = seed[0].cfo_c, cfo_f = seed[0].cfo_f;
+    int   fs = seed[0].fs;
+    uint32_t flags = seed[0].flags;
+#pragma unroll
+    for (int f = 1; f < 4; f++) {
+        if (row == f) {
+            x = seed[f].x; n_samp = seed[f].n_samp; t16 = seed[f].t - 16; L = seed[f].L; out = seed[f].out;
+            cfo_c = seed[f].cfo_c; cfo_f = seed[f].cfo_f; fs = seed[f].fs; flags = seed[f].flags;
+        }
+    }
+    bool alive = (out >= 0) && (flags & WIFIRX_F_SYNC);
+    const double bw = prm.bandwidth, fc = prm.frequency;
+    const double two_pi = 2 * 3.14159265358979323846;
+    const double tag = (double)cfo_c - (double)cfo_f;
+    const double eps0 = tag * bw / (two_pi * fc);
+    const double er_scale = bw / (two_pi * fc * 80);
+    double d_er = 0.0;
+    c32 prev0 = { 0, 0 }, prev1 = { 0, 0 }, prev2 = { 0, 0 }, prev3 = { 0, 0 };
+    c32 H[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+    int n_sym = 0, n_bpsc = 1, n_out = 0, enc = 0, psdu_len = 0;
+    bool have_signal = false, want_llr = false;
+    float snr = 0.0f;
+
+    // ---- lane constants ----
+    int   carrier[4];
+    bool  used[4];
+    float lts[4];
+    c32   tw1[4], tw2[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int i = r + 16 * j;
+        bool data = (i >= 6 && i <= 58 && i != 11 && i != 25 && i != 32 && i != 39 && i != 53);
+        carrier[j] = data ? (i - 6 - (i > 11) - (i > 25) - (i > 32) - (i > 39) - (i > 53)) : -1;
+        used[j] = (i >= 6 && i <= 58 && i != 32);
+        lts[j] = WR_LTS_FREQ[i];
+        int e1 = (j * r) & 63;                       // stage 1: output q=j of the butterfly at n = r
+        tw1[j] = { WR_TWIDDLE64[2 * e1], WR_TWIDDLE64[2 * e1 + 1] };
+        int e2 = (j * (r & 3) * 4) & 63;             // stage 2: lane (q1 = r>>2, m = r&3), output q2 = j
+        tw2[j] = { WR_TWIDDLE64[2 * e2], WR_TWIDDLE64[2 * e2 + 1] };
+    }
+    // LDS transposes: every row owns 64 complex slots (+8 floats of padding between rows)
+    float* rowl = qlds + row * 136;
+    const int wA = r;                                 // stage-1 output q of lane r  -> position r + 16 q
+    const int rA = 16 * (r >> 2) + (r & 3);           // stage-2 input j of lane (q1,m) <- position 16 q1 + m + 4 j
+    const int wB = rA;                                // stage-2 output q2 of lane (q1,m) -> position 16 q1 + m + 4 q2
+    const int rB = 16 * (r & 3) + 4 * (r >> 2);       // stage-3 input j of lane r (q1 = r&3, q2 = r>>2) <- 16 q1 + 4 q2 + j
+
+    const size_t per = (size_t)prm.max_sym * 48;
+    uint8_t* idx = (idx_all && out >= 0) ? idx_all + out * per : nullptr;
+    float*   llr = (llr_all && out >= 0) ? llr_all + out * per * prm.llr_bits : nullptr;
+    float2*  car = (car_all && out >= 0) ? car_all + out * per : nullptr;
+
+    for (int s = 0;; s++) {
+        long off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
+        bool act = alive && (s <= n_sym + 2);
+        if (act && (off0 + 64 > L || (s > 2 && (s - 3) >= (int)prm.max_sym))) {
+            flags |= WIFIRX_F_TRUNCATED;
+            alive = false;
+            act = false;
+        }
+        if (!__any(act)) break;
+
+        // ---- samples r + 16 j of the symbol, two derotations each (sync_short / sync_long copy) ----
+        c32 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            long m = off0 + r + 16 * j;
+            c32 xs = act ? load_sample(x, t16 + m, n_samp) : c32{ 0.0f, 0.0f };
+            float s1, c1, s2, c2;
+            sp_sincos(-cfo_c * (float)m, s1, c1);
+            sp_sincos((float)m * cfo_f, s2, c2);
+            v[j] = sp_rot(sp_rot(xs, s1, c1), s2, c2);
+        }
+        // ---- FFT-64: three in-register radix-4 stages, two transposes through LDS ----
+        bfly4_reg(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            c32 y = (j == 0) ? v[0] : sp_cmul(v[j], tw1[j]);
+            rowl[2 * (wA + 16 * j)] = y.re;
+            rowl[2 * (wA + 16 * j) + 1] = y.im;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = { rowl[2 * (rA + 4 * j)], rowl[2 * (rA + 4 * j) + 1] };
+        __builtin_amdgcn_wave_barrier();
+        bfly4_reg(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            c32 y = (j == 0) ? v[0] : sp_cmul(v[j], tw2[j]);
+            rowl[2 * (wB + 4 * j)] = y.re;
+            rowl[2 * (wB + 4 * j) + 1] = y.im;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = { rowl[2 * (rB + j)], rowl[2 * (rB + j) + 1] };
+        __builtin_amdgcn_wave_barrier();
+        bfly4_reg(v[0], v[1], v[2], v[3]);
+        // stage-3 output q3 is sub-carrier k = r + 16 q3, i.e. shifted bin i = r + 16 ((q3 + 2) & 3)
+        c32 X[4] = { v[2], v[3], v[0], v[1] };
+
+        // (1) sampling offset
+        {
+            double t4 = two_pi * s * 80 * (eps0 + d_er);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float ang = (float)(t4 * (double)(r + 16 * j - 32) / 64);
+                float sn, cs;
+                sp_sincos(ang, sn, cs);
+                X[j] = sp_rot(X[j], sn, cs);
+            }
+        }
+        // (2) pilots: bins 11, 25, 39, 53 = (lane 11, j 0), (lane 9, j 1), (lane 7, j 2), (lane 5, j 3)
+        c32 X11 = row_bcast<11>(X[0]), X25 = row_bcast<9>(X[1]), X39 = row_bcast<7>(X[2]), X53 = row_bcast<5>(X[3]);
+        bool pneg = (s >= 2) && (WR_POLARITY[(s - 2) % 127] < 0);
+        c32 S;
+        if (s < 2) S = cadd(cadd(csub(X11, X25), X39), X53);
+        else {
+            S = csub(cadd(cadd(X11, X39), X25), X53);
+            if (pneg) S = cneg(S);
+        }
+        float beta = sp_atan2(S.im, S.re);
+        // (3) residual offset estimate
+        c32 cur0, cur1, cur2, cur3;
+        if (s < 2) { cur0 = X11; cur1 = cneg(X25); cur2 = X39; cur3 = X53; }
+        else {
+            cur0 = pneg ? cneg(X11) : X11;
+            cur1 = pneg ? cneg(X25) : X25;
+            cur2 = pneg ? cneg(X39) : X39;
+            cur3 = pneg ? X53 : cneg(X53);
+        }
+        double er = 0.0;
+        if (s >= 2) {
+            c32 acc = cadd(cadd(cadd(sp_conj_mul(prev0, cur0), sp_conj_mul(prev1, cur1)),
+                                sp_conj_mul(prev2, cur2)), sp_conj_mul(prev3, cur3));
+            er = (double)sp_atan2(acc.im, acc.re) * er_scale;
+        }
+        prev0 = cur0; prev1 = cur1; prev2 = cur2; prev3 = cur3;
+        // (4) common phase
+        {
+            float sn, cs;
+            sp_sincos(-beta, sn, cs);
+#pragma unroll
+            for (int j = 0; j < 4; j++) X[j] = sp_rot(X[j], sn, cs);
+        }
+        // (5) IIR
+        if (s >= 2) {
+            double alpha = 0.1;
+            d_er = (1 - alpha) * d_er + alpha * er;
+        }
+        // (6) LS equalizer
+        if (s == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) H[j] = X[j];
+        } else if (s == 1) {
+            float nv[4], sv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                c32 d = csub(H[j], X[j]), u = cadd(H[j], X[j]);
+                nv[j] = used[j] ? fma_(d.im, d.im, d.re * d.re) : 0.0f;
+                sv[j] = used[j] ? fma_(u.im, u.im, u.re * u.re) : 0.0f;
+                float g = 0.5f * lts[j];
+                if (used[j]) { H[j].re = u.re * g; H[j].im = u.im * g; }
+                // the spec's xor tree over the 64 bins: steps 1,2,4,8 inside the row ...
+                nv[j] = row_xor_sum16(nv[j]);
+                sv[j] = row_xor_sum16(sv[j]);
+            }
+            // ... step 16 pairs bins i, i^16 (registers j, j^1), step 32 pairs registers j, j^2
+            float n01 = nv[0] + nv[1], n23 = nv[2] + nv[3], s01 = sv[0] + sv[1], s23 = sv[2] + sv[3];
+            float noise = n01 + n23, signal = s01 + s23;
+            if (act) snr = sp_snr_db(signal, noise);
+        } else {
+            int nb = (s == 2) ? 1 : n_bpsc;
+            c32 Y[4];
+            uint8_t bits[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                Y[j] = { 0.0f, 0.0f };
+                if (carrier[j] >= 0) {
+                    float d = fma_(H[j].im, H[j].im, H[j].re * H[j].re);
+                    Y[j].re = fma_(X[j].im, H[j].im, X[j].re * H[j].re) / d;
+                    Y[j].im = fma_(X[j].im, H[j].re, -(X[j].re * H[j].im)) / d;
+                }
+                bits[j] = decide(Y[j], nb);
+            }
+            if (s == 2) {
+                // (7) SIGNAL: per frame, gather the 48 decisions in carrier order, de-interleave, Viterbi
+                uint64_t bal[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) bal[j] = __ballot(carrier[j] >= 0 && (bits[j] & 1));
+                const uint64_t actmask = __ballot(act);
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    if (!((actmask >> (16 * f)) & 1)) continue;
+                    uint64_t b = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) b |= ((bal[j] >> (16 * f)) & 0xffffull) << (16 * j);
+                    uint64_t cm = ((b >> 6) & 0x1full) | (((b >> 12) & 0x1fffull) << 5) |
+                                  (((b >> 26) & 0x3full) << 18) | (((b >> 33) & 0x3full) << 24) |
+                                  (((b >> 40) & 0x1fffull) << 30) | (((b >> 54) & 0x1full) << 43);
+                    uint64_t de = 0;
+#pragma unroll
+                    for (int jj = 0; jj < 48; jj++) de |= ((cm >> (3 * (jj % 16) + jj / 16)) & 1ull) << jj;
+                    uint32_t sig = viterbi_signal(de, lane);
+                    int e = 0, len = 0;
+                    bool ok = parse_signal(sig, e, len);
+                    if (row == f) {
+                        if (!ok) {
+                            alive = false;
+                        } else {
+                            const int nbpsc_tab[8] = { 1, 1, 2, 2, 4, 4, 6, 6 };
+                            const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
+                            have_signal = true;
+                            enc = e;
+                            psdu_len = len;
+                            n_bpsc = nbpsc_tab[e];
+                            int nd = ndbps_tab[e];
+                            n_sym = (16 + 8 * len + 6 + nd - 1) / nd;
+                            flags |= WIFIRX_F_SIGNAL;
+                            want_llr = (llr != nullptr) && ((int)prm.llr_bits >= n_bpsc);
+                            if (want_llr) flags |= WIFIRX_F_LLR;
+                        }
+                    }
+                }
+            } else if (act) {
+                // (8) data symbol q
+                int q = s - 3;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (carrier[j] < 0) continue;
+                    size_t o = (size_t)q * 48 + carrier[j];
+                    if (idx) idx[o] = bits[j];
+                    if (car) car[o] = make_float2(Y[j].re, Y[j].im);
+                    if (want_llr) {
+                        float are = __builtin_fabsf(Y[j].re), aim = __builtin_fabsf(Y[j].im);
+                        float* lp = llr + o * n_bpsc;
+                        if (n_bpsc == 1) {
+                            lp[0] = Y[j].re;
+                        } else if (n_bpsc == 2) {
+                            *reinterpret_cast<float2*>(lp) = make_float2(Y[j].re, Y[j].im);
+                        } else if (n_bpsc == 4) {
+                            *reinterpret_cast<float4*>(lp) = make_float4(Y[j].re, WR_T16_2 - are, Y[j].im, WR_T16_2 - aim);
+                        } else {
+                            float2* l2 = reinterpret_cast<float2*>(lp);
+                            l2[0] = make_float2(Y[j].re, WR_T64_4 - are);
+                            l2[1] = make_float2(WR_T64_2 - __builtin_fabsf(are - WR_T64_4), Y[j].im);
+                            l2[2] = make_float2(WR_T64_4 - aim, WR_T64_2 - __builtin_fabsf(aim - WR_T64_4));
+                        }
+                    }
+                }
+                n_out = q + 1;
+            }
+        }
+    }
+    if (r == 0 && out >= 0) {
+        wifirx_frame fr;
+        if (have_signal && n_out == n_sym) flags |= WIFIRX_F_COMPLETE;
+        bool sync = (flags & WIFIRX_F_SYNC) != 0;
+        fr.flags = flags;
+        fr.trigger = (int32_t)(t16 + 16);
+        fr.frame_start = sync ? fs : 0;
+        fr.cfo_coarse = (flags & WIFIRX_F_DETECTED) ? cfo_c : 0.0f;
+        fr.cfo_fine = sync ? cfo_f : 0.0f;
+        fr.snr_db = snr;
+        fr.psdu_len = (uint16_t)psdu_len;
+        fr.encoding = (uint8_t)enc;
+        fr.n_bpsc = have_signal ? (uint8_t)n_bpsc : 0;
+        fr.n_sym = (uint16_t)n_sym;
+        fr.n_sym_out = (uint16_t)n_out;
+        frames[out] = fr;
+    }
+}
+
+}  // namespace wr
