@@ -113,25 +113,19 @@ __device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n
 // batch kernel: one wave = 4 consecutive slots, WR_WAVES_PER_BLOCK waves per workgroup.
 // Preamble phase per slot with the whole wave (lane = sample / lag), then the four frames walk their
 // symbols together (wr_quad.h).
-__device__ __forceinline__ FrameSeed seed_none()
+// sync_short found trigger t in (x, n_samp): run the LTS search when enough samples were copied.
+// All arguments wave-uniform; returns the frame's flags.
+__device__ __forceinline__ uint32_t sync_after_trigger(const float2* x, long n_samp, long t, long L, float cfo_c,
+                                                       float* lds, int lane, int& fs, float& cfo_f)
 {
-    FrameSeed sd;
-    sd.x = nullptr; sd.n_samp = 0; sd.t = -1; sd.L = 0; sd.cfo_c = 0.0f; sd.cfo_f = 0.0f; sd.fs = 0; sd.flags = 0; sd.out = -1;
-    return sd;
+    fs = 0;
+    cfo_f = 0.0f;
+    if (L < WIFIRX_SYNC_LENGTH + 63) return WIFIRX_F_DETECTED | WIFIRX_F_TRUNCATED;
+    bool ok = preamble_sync(x, n_samp, t, cfo_c, lds, lane, fs, cfo_f);
+    return ok ? (WIFIRX_F_DETECTED | WIFIRX_F_SYNC) : WIFIRX_F_DETECTED;
 }
 
-// sync_short found trigger t in (x, n_samp): run the LTS search when enough samples were copied
-__device__ __forceinline__ void seed_sync(FrameSeed& sd, float* lds, int lane)
-{
-    sd.flags = WIFIRX_F_DETECTED;
-    if (sd.L < WIFIRX_SYNC_LENGTH + 63) {
-        sd.flags |= WIFIRX_F_TRUNCATED;
-        return;
-    }
-    if (preamble_sync(sd.x, sd.n_samp, sd.t, sd.cfo_c, lds, lane, sd.fs, sd.cfo_f)) sd.flags |= WIFIRX_F_SYNC;
-}
-
-__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK)
+__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, WR_DEMOD_WAVES_PER_SIMD)
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
                         DemodParams prm, wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
                         float* __restrict__ llr, float2* __restrict__ carrier)
@@ -141,24 +135,27 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
     const int wave = threadIdx.x >> 6;
     const uint32_t slot0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;
     if (slot0 >= n_slots) return;
-    FrameSeed seed[4];
-#pragma unroll
+    QuadSeed seed = quad_seed_none();
     for (int f = 0; f < 4; f++) {
-        seed[f] = seed_none();
         const uint32_t slot = slot0 + f;
-        if (slot >= n_slots) continue;
-        FrameSeed& sd = seed[f];
-        sd.x = iq + (size_t)slot * slot_len;
-        sd.n_samp = slot_len;
-        sd.out = slot;
+        if (slot >= n_slots) break;
+        const float2* x = iq + (size_t)slot * slot_len;
         c32 A_t = { 0, 0 };
-        int t = detect_first(sd.x, slot_len, prm.threshold, prm.min_plateau, lane, A_t);
-        sd.t = t;
-        if (t < 0) continue;
-        sd.cfo_c = sp_atan2(A_t.im, A_t.re) / 16.0f;
-        long L = (long)slot_len - (t - 16);
-        sd.L = L > WIFIRX_MAX_SAMPLES ? WIFIRX_MAX_SAMPLES : L;
-        seed_sync(sd, lds[wave], lane);
+        int t = detect_first(x, slot_len, prm.threshold, prm.min_plateau, lane, A_t);
+        float cfo_c = 0.0f, cfo_f = 0.0f;
+        int fs = 0;
+        long L = 0;
+        uint32_t flags = 0;
+        if (t >= 0) {
+            cfo_c = sp_atan2(A_t.im, A_t.re) / 16.0f;
+            L = (long)slot_len - (t - 16);
+            if (L > WIFIRX_MAX_SAMPLES) L = WIFIRX_MAX_SAMPLES;
+            flags = sync_after_trigger(x, slot_len, t, L, cfo_c, lds[wave], lane, fs, cfo_f);
+        }
+        if ((lane >> 4) == f) {
+            seed.x = x; seed.n_samp = slot_len; seed.t = t; seed.L = L; seed.cfo_c = cfo_c; seed.cfo_f = cfo_f;
+            seed.fs = fs; seed.flags = flags; seed.out = slot;
+        }
     }
     frames_quad(seed, prm, lds[wave], lane, frames, idx, llr, carrier);
 }
@@ -189,7 +186,7 @@ void stream_detect_kernel(const float2* __restrict__ x, long n_samp, long tile0,
 }
 
 // one wave per four selected triggers of the stream
-__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK)
+__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, WR_DEMOD_WAVES_PER_SIMD)
 void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const StreamTrig* __restrict__ trig,
                          uint32_t n_trig, DemodParams prm, const float2* __restrict__ A,
                          wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
@@ -200,25 +197,23 @@ void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const Stream
     const int wave = threadIdx.x >> 6;
     const uint32_t k0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;
     if (k0 >= n_trig) return;
-    FrameSeed seed[4];
-#pragma unroll
+    QuadSeed seed = quad_seed_none();
     for (int f = 0; f < 4; f++) {
-        seed[f] = seed_none();
         const uint32_t k = k0 + f;
-        if (k >= n_trig) continue;
+        if (k >= n_trig) break;
         const StreamTrig tg = trig[k];
-        FrameSeed& sd = seed[f];
-        sd.x = x;
-        sd.n_samp = n_samp;
-        sd.out = k;
-        sd.t = tg.pos;
-        sd.L = tg.usable;
-        sd.cfo_c = tg.cfo;                 // carried over from an earlier push of the same stream
+        float cfo_c = tg.cfo;              // carried over from an earlier push of the same stream
         if (!tg.pad) {
             const float2 At = A[tg.pos];
-            sd.cfo_c = sp_atan2(At.y, At.x) / 16.0f;
+            cfo_c = sp_atan2(At.y, At.x) / 16.0f;
         }
-        seed_sync(sd, lds[wave], lane);
+        float cfo_f;
+        int fs;
+        uint32_t flags = sync_after_trigger(x, n_samp, tg.pos, tg.usable, cfo_c, lds[wave], lane, fs, cfo_f);
+        if ((lane >> 4) == f) {
+            seed.x = x; seed.n_samp = n_samp; seed.t = tg.pos; seed.L = tg.usable; seed.cfo_c = cfo_c; seed.cfo_f = cfo_f;
+            seed.fs = fs; seed.flags = flags; seed.out = k;
+        }
     }
     frames_quad(seed, prm, lds[wave], lane, frames, idx, llr, carrier);
 }

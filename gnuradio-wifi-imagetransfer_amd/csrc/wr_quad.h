@@ -20,7 +20,20 @@
 
 namespace wr {
 
-#define WR_QLDS_FLOATS 768          // per wave: max(383 preamble samples, 4 rows x 64 values) complex
+// Keeps the instruction scheduler from interleaving the four independent per-sample chains of a lane:
+// interleaved they need ~190 VGPRs (2 waves/SIMD); one after the other the kernel fits 4-5 waves/SIMD,
+// and waves, not chains, hide the latencies.
+#ifndef WR_PREFETCH
+#define WR_PREFETCH 0      // 1: load the next symbol's samples one iteration ahead (+8 VGPRs)
+#endif
+#ifndef WR_SCHED_FENCE
+#define WR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+#define WR_QLDS_SCRATCH 768
+#define WR_QLDS_H       (WR_QLDS_SCRATCH)            // 4 x 64 float2: channel estimate, lane-private slots
+#define WR_QLDS_TW      (WR_QLDS_H + 512)              // 6 x 16 float2: stage-1/2 twiddles by row lane
+#define WR_QLDS_FLOATS  (WR_QLDS_TW + 192)          // per wave: max(383 preamble samples, 4 rows x 64 values) complex
 
 __device__ __forceinline__ c32 load_sample(const float2* __restrict__ x, long n, long n_samp)
 {
@@ -197,8 +210,9 @@ __device__ __forceinline__ bool preamble_sync(const float2* __restrict__ x, long
     return found != 0;
 }
 
-// what the preamble phase hands to the symbol phase for one frame (all wave-uniform)
-struct FrameSeed {
+// What the preamble phase hands to the symbol phase.  One copy per lane, uniform inside a row: row f
+// of the wave takes the values of frame f, so nothing wave-uniform has to be kept for four frames at once.
+struct QuadSeed {
     const float2* x;      // stream / slot the frame lives in
     long     n_samp;
     long     t;           // trigger index, -1: no frame in this row
@@ -209,6 +223,13 @@ struct FrameSeed {
     uint32_t flags;       // DETECTED [| SYNC] [| TRUNCATED]
     long     out;         // index of the frame's record / output slices, -1: none
 };
+
+__device__ __forceinline__ QuadSeed quad_seed_none()
+{
+    QuadSeed q;
+    q.x = nullptr; q.n_samp = 0; q.t = -1; q.L = 0; q.cfo_c = 0.0f; q.cfo_f = 0.0f; q.fs = 0; q.flags = 0; q.out = -1;
+    return q;
+}
 
 // in-register 4-point DIF butterfly (spec section 4.4)
 __device__ __forceinline__ void bfly4_reg(c32& a, c32& b, c32& c, c32& d)
@@ -240,24 +261,17 @@ __device__ __forceinline__ float row_xor_sum16(float v)
 
 // ---------------------------------------------------------------------------------------------
 // a3 copy + a4 + a5 + a6 + a7 for the four frames of a wave.
-__device__ __forceinline__ void frames_quad(const FrameSeed (&seed)[4], const DemodParams& prm, float* qlds, int lane,
+__device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodParams& prm, float* qlds, int lane,
                                             wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx_all,
                                             float* __restrict__ llr_all, float2* __restrict__ car_all)
 {
     const int row = lane >> 4, r = lane & 15;
     // ---- row-uniform frame state, one copy per lane ----
-    const float2* x = seed[0].x;
-    long  n_samp = seed[0].n_samp, t16 = seed[0].t - 16, L = seed[0].L, out = seed[0].out;
-    float cfo_c = seed[0].cfo_c, cfo_f = seed[0].cfo_f;
-    int   fs = seed[0].fs;
-    uint32_t flags = seed[0].flags;
-#pragma unroll
-    for (int f = 1; f < 4; f++) {
-        if (row == f) {
-            x = seed[f].x; n_samp = seed[f].n_samp; t16 = seed[f].t - 16; L = seed[f].L; out = seed[f].out;
-            cfo_c = seed[f].cfo_c; cfo_f = seed[f].cfo_f; fs = seed[f].fs; flags = seed[f].flags;
-        }
-    }
+    const float2* x = seed.x;
+    const long  n_samp = seed.n_samp, t16 = seed.t - 16, L = seed.L, out = seed.out;
+    const float cfo_c = seed.cfo_c, cfo_f = seed.cfo_f;
+    const int   fs = seed.fs;
+    uint32_t flags = seed.flags;
     bool alive = (out >= 0) && (flags & WIFIRX_F_SYNC);
     const double bw = prm.bandwidth, fc = prm.frequency;
     const double two_pi = 2 * 3.14159265358979323846;
@@ -266,39 +280,49 @@ __device__ __forceinline__ void frames_quad(const FrameSeed (&seed)[4], const De
     const double er_scale = bw / (two_pi * fc * 80);
     double d_er = 0.0;
     c32 prev0 = { 0, 0 }, prev1 = { 0, 0 }, prev2 = { 0, 0 }, prev3 = { 0, 0 };
-    c32 H[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
     int n_sym = 0, n_bpsc = 1, n_out = 0, enc = 0, psdu_len = 0;
     bool have_signal = false, want_llr = false;
     float snr = 0.0f;
 
-    // ---- lane constants ----
-    int   carrier[4];
-    bool  used[4];
-    float lts[4];
-    c32   tw1[4], tw2[4];
+    // ---- twiddles of stage 1 (output q = j at n = r) and stage 2 (lane (q1 = r>>2, m = r&3)): a 6 x 16 table in
+    //      LDS, read back every symbol (registers are the scarce resource of this kernel, the LDS pipe is idle) ----
+    float2* twl = reinterpret_cast<float2*>(qlds + WR_QLDS_TW);
+    if (row == 0) {
+#pragma unroll
+        for (int j = 1; j < 4; j++) {
+            int e1 = (j * r) & 63, e2 = (j * (r & 3) * 4) & 63;
+            twl[(j - 1) * 16 + r] = make_float2(WR_TWIDDLE64[2 * e1], WR_TWIDDLE64[2 * e1 + 1]);
+            twl[(j + 2) * 16 + r] = make_float2(WR_TWIDDLE64[2 * e2], WR_TWIDDLE64[2 * e2 + 1]);
+        }
+    }
+    float2* Hl = reinterpret_cast<float2*>(qlds + WR_QLDS_H) + lane;      // element j at Hl[64 j]
+    int carrier0[4];                     // data carrier number 0..47 of bin r + 16 j, -1 for pilots / DC / guards
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        int i = r + 16 * j;
-        bool data = (i >= 6 && i <= 58 && i != 11 && i != 25 && i != 32 && i != 39 && i != 53);
-        carrier[j] = data ? (i - 6 - (i > 11) - (i > 25) - (i > 32) - (i > 39) - (i > 53)) : -1;
-        used[j] = (i >= 6 && i <= 58 && i != 32);
-        lts[j] = WR_LTS_FREQ[i];
-        int e1 = (j * r) & 63;                       // stage 1: output q=j of the butterfly at n = r
-        tw1[j] = { WR_TWIDDLE64[2 * e1], WR_TWIDDLE64[2 * e1 + 1] };
-        int e2 = (j * (r & 3) * 4) & 63;             // stage 2: lane (q1 = r>>2, m = r&3), output q2 = j
-        tw2[j] = { WR_TWIDDLE64[2 * e2], WR_TWIDDLE64[2 * e2 + 1] };
+        const int i = r + 16 * j;
+        const bool data = (i >= 6 && i <= 58 && i != 11 && i != 25 && i != 32 && i != 39 && i != 53);
+        carrier0[j] = data ? (i - 6 - (i > 11) - (i > 25) - (i > 32) - (i > 39) - (i > 53)) : -1;
     }
-    // LDS transposes: every row owns 64 complex slots (+8 floats of padding between rows)
-    float* rowl = qlds + row * 136;
-    const int wA = r;                                 // stage-1 output q of lane r  -> position r + 16 q
-    const int rA = 16 * (r >> 2) + (r & 3);           // stage-2 input j of lane (q1,m) <- position 16 q1 + m + 4 j
-    const int wB = rA;                                // stage-2 output q2 of lane (q1,m) -> position 16 q1 + m + 4 q2
-    const int rB = 16 * (r & 3) + 4 * (r >> 2);       // stage-3 input j of lane r (q1 = r&3, q2 = r>>2) <- 16 q1 + 4 q2 + j
-
+    __builtin_amdgcn_wave_barrier();
+    // LDS transposes (8-byte elements).  Element (hi, mid, lo) of a row lives at
+    //   128*(row>>1) + 32*hi + 16*(row&1) + 4*mid + (hi ^ lo):
+    // the 32 lanes of a row pair hit 32 different 8-byte banks both when a register index is fixed and
+    // the lane pair (mid, lo) varies and when lo is fixed and (hi, mid) varies.
+    float2* ql = reinterpret_cast<float2*>(qlds) + 128 * (row >> 1) + 16 * (row & 1);
+    const int m4 = 4 * (r & 3), c2 = r >> 2;
+    // transpose A: stage-1 output q of lane r=(m, c) is element (q, m, c); lane (q1=c2, m) reads (q1, m, j)
+    // transpose B: stage-2 output q2 of lane (q1=c2, m) is element (q2, q1, m); lane (q1=r&3, q2=c2) reads (q2, q1, j)
     const size_t per = (size_t)prm.max_sym * 48;
     uint8_t* idx = (idx_all && out >= 0) ? idx_all + out * per : nullptr;
     float*   llr = (llr_all && out >= 0) ? llr_all + out * per * prm.llr_bits : nullptr;
     float2*  car = (car_all && out >= 0) ? car_all + out * per : nullptr;
+
+    // samples of symbol 0, then always one symbol ahead of the arithmetic (hides the HBM latency that
+    // 2-4 waves per SIMD cannot); loads are bounds-checked only, a symbol that turns out not to exist
+    // is simply not used
+    c32 nx[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) nx[j] = WR_PREFETCH ? load_sample(x, t16 + fs + r + 16 * j, n_samp) : c32{ 0.0f, 0.0f };
 
     for (int s = 0;; s++) {
         long off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
@@ -311,11 +335,24 @@ __device__ __forceinline__ void frames_quad(const FrameSeed (&seed)[4], const De
         if (!__any(act)) break;
 
         // ---- samples r + 16 j of the symbol, two derotations each (sync_short / sync_long copy) ----
-        c32 v[4];
+        c32 v[4], cur[4];
+        {
+            const long offn = fs + (s + 1 < 2 ? 64 * (s + 1) : 128 + 80 * (s - 1) + 16);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#if WR_PREFETCH
+                cur[j] = nx[j];
+                nx[j] = load_sample(x, t16 + offn + r + 16 * j, n_samp);
+#else
+                (void)offn;
+                cur[j] = act ? load_sample(x, t16 + off0 + r + 16 * j, n_samp) : c32{ 0.0f, 0.0f };
+#endif
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             long m = off0 + r + 16 * j;
-            c32 xs = act ? load_sample(x, t16 + m, n_samp) : c32{ 0.0f, 0.0f };
+            c32 xs = act ? cur[j] : c32{ 0.0f, 0.0f };
             float s1, c1, s2, c2;
             sp_sincos(-cfo_c * (float)m, s1, c1);
             sp_sincos((float)m * cfo_f, s2, c2);
@@ -325,24 +362,30 @@ __device__ __forceinline__ void frames_quad(const FrameSeed (&seed)[4], const De
         bfly4_reg(v[0], v[1], v[2], v[3]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            c32 y = (j == 0) ? v[0] : sp_cmul(v[j], tw1[j]);
-            rowl[2 * (wA + 16 * j)] = y.re;
-            rowl[2 * (wA + 16 * j) + 1] = y.im;
+            c32 y = v[0];
+            if (j) { float2 w = twl[(j - 1) * 16 + r]; y = sp_cmul(v[j], c32{ w.x, w.y }); }
+            ql[32 * j + m4 + (j ^ c2)] = make_float2(y.re, y.im);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = { rowl[2 * (rA + 4 * j)], rowl[2 * (rA + 4 * j) + 1] };
+        for (int j = 0; j < 4; j++) {
+            float2 t = ql[32 * c2 + m4 + (c2 ^ j)];
+            v[j] = { t.x, t.y };
+        }
         __builtin_amdgcn_wave_barrier();
         bfly4_reg(v[0], v[1], v[2], v[3]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            c32 y = (j == 0) ? v[0] : sp_cmul(v[j], tw2[j]);
-            rowl[2 * (wB + 4 * j)] = y.re;
-            rowl[2 * (wB + 4 * j) + 1] = y.im;
+            c32 y = v[0];
+            if (j) { float2 w = twl[(j + 2) * 16 + r]; y = sp_cmul(v[j], c32{ w.x, w.y }); }
+            ql[32 * j + 4 * c2 + (j ^ (r & 3))] = make_float2(y.re, y.im);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = { rowl[2 * (rB + j)], rowl[2 * (rB + j) + 1] };
+        for (int j = 0; j < 4; j++) {
+            float2 t = ql[32 * c2 + m4 + (c2 ^ j)];
+            v[j] = { t.x, t.y };
+        }
         __builtin_amdgcn_wave_barrier();
         bfly4_reg(v[0], v[1], v[2], v[3]);
         // stage-3 output q3 is sub-carrier k = r + 16 q3, i.e. shifted bin i = r + 16 ((q3 + 2) & 3)
@@ -353,7 +396,9 @@ __device__ __forceinline__ void frames_quad(const FrameSeed (&seed)[4], const De
             double t4 = two_pi * s * 80 * (eps0 + d_er);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                float ang = (float)(t4 * (double)(r + 16 * j - 32) / 64);
+                int kk = r + 16 * j - 32;
+                asm volatile("" : "+v"(kk));
+                float ang = (float)(t4 * (double)kk / 64);
                 float sn, cs;
                 sp_sincos(ang, sn, cs);
                 X[j] = sp_rot(X[j], sn, cs);
@@ -400,16 +445,20 @@ __device__ __forceinline__ void frames_quad(const FrameSeed (&seed)[4], const De
         // (6) LS equalizer
         if (s == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) H[j] = X[j];
+            for (int j = 0; j < 4; j++) Hl[64 * j] = make_float2(X[j].re, X[j].im);
         } else if (s == 1) {
             float nv[4], sv[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                c32 d = csub(H[j], X[j]), u = cadd(H[j], X[j]);
-                nv[j] = used[j] ? fma_(d.im, d.im, d.re * d.re) : 0.0f;
-                sv[j] = used[j] ? fma_(u.im, u.im, u.re * u.re) : 0.0f;
-                float g = 0.5f * lts[j];
-                if (used[j]) { H[j].re = u.re * g; H[j].im = u.im * g; }
+                const float2 h0 = Hl[64 * j];
+                const c32 Hj = { h0.x, h0.y };
+                c32 d = csub(Hj, X[j]), u = cadd(Hj, X[j]);
+                const int i = r + 16 * j;
+                const bool usedj = (i >= 6 && i <= 58 && i != 32);
+                nv[j] = usedj ? fma_(d.im, d.im, d.re * d.re) : 0.0f;
+                sv[j] = usedj ? fma_(u.im, u.im, u.re * u.re) : 0.0f;
+                float g = 0.5f * WR_LTS_FREQ[i];
+                if (usedj) Hl[64 * j] = make_float2(u.re * g, u.im * g);
                 // the spec's xor tree over the 64 bins: steps 1,2,4,8 inside the row ...
                 nv[j] = row_xor_sum16(nv[j]);
                 sv[j] = row_xor_sum16(sv[j]);
@@ -422,15 +471,20 @@ __device__ __forceinline__ void frames_quad(const FrameSeed (&seed)[4], const De
             int nb = (s == 2) ? 1 : n_bpsc;
             c32 Y[4];
             uint8_t bits[4];
+            int carrier[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                carrier[j] = carrier0[j];
+                asm volatile("" : "+v"(carrier[j]));     // keeps base + carrier out of loop-invariant registers
                 Y[j] = { 0.0f, 0.0f };
                 if (carrier[j] >= 0) {
-                    float d = fma_(H[j].im, H[j].im, H[j].re * H[j].re);
-                    Y[j].re = fma_(X[j].im, H[j].im, X[j].re * H[j].re) / d;
-                    Y[j].im = fma_(X[j].im, H[j].re, -(X[j].re * H[j].im)) / d;
+                    const float2 h0 = Hl[64 * j];
+                    float d = fma_(h0.y, h0.y, h0.x * h0.x);
+                    Y[j].re = fma_(X[j].im, h0.y, X[j].re * h0.x) / d;
+                    Y[j].im = fma_(X[j].im, h0.x, -(X[j].re * h0.y)) / d;
                 }
                 bits[j] = decide(Y[j], nb);
+                WR_SCHED_FENCE();       // one bin's two divisions at a time: the 8 interleaved need ~40 more VGPRs
             }
             if (s == 2) {
                 // (7) SIGNAL: per frame, gather the 48 decisions in carrier order, de-interleave, Viterbi
