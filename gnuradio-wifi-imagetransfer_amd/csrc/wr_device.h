@@ -40,6 +40,28 @@ __device__ __forceinline__ void sp_sincos(float x, float& s, float& c)
     c = ((k + 1) & 2) ? -c0 : c0;
 }
 
+// sine/cosine of a double angle: reduction by pi/2 in double, polynomials in float (spec section 4.1)
+__device__ __forceinline__ void sp_sincos_d(double x, float& s, float& c)
+{
+    double kd = __builtin_rint(x * WR_TWO_OVER_PI_D);
+    int    k  = (int)kd;
+    double rd = __builtin_fma(-kd, WR_PIO2_D_HI, x);
+    rd = __builtin_fma(-kd, WR_PIO2_D_LO, rd);
+    float r  = (float)rd;
+    float z  = r * r;
+    float ps = fma_(z, WR_S3, WR_S2);
+    ps = fma_(ps, z, WR_S1);
+    float sr = fma_(ps * z, r, r);
+    float pc = fma_(z, WR_C3, WR_C2);
+    pc = fma_(pc, z, WR_C1);
+    float cr = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
+    bool  odd = k & 1;
+    float s0 = odd ? cr : sr;
+    float c0 = odd ? sr : cr;
+    s = (k & 2) ? -s0 : s0;
+    c = ((k + 1) & 2) ? -c0 : c0;
+}
+
 __device__ __forceinline__ float sp_atan2(float y, float x)
 {
     float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);

@@ -279,6 +279,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     const double eps0 = tag * bw / (two_pi * fc);
     const double er_scale = bw / (two_pi * fc * 80);
     double d_er = 0.0;
+    const double theta_d = (double)cfo_f - (double)cfo_c;      // total derotation, rad/sample
+    c32 u16;                                                   // exp(j theta 16)
+    sp_sincos_d(theta_d * 16.0, u16.im, u16.re);
     c32 prev0 = { 0, 0 }, prev1 = { 0, 0 }, prev2 = { 0, 0 }, prev3 = { 0, 0 };
     int n_sym = 0, n_bpsc = 1, n_out = 0, enc = 0, psdu_len = 0;
     bool have_signal = false, want_llr = false;
@@ -349,14 +352,15 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #endif
             }
         }
+        {   // one rotation by the total offset: base phasor from a double angle, then steps of exp(j theta 16)
+            c32 w;
+            sp_sincos_d(theta_d * (double)(off0 + r), w.im, w.re);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            long m = off0 + r + 16 * j;
-            c32 xs = act ? cur[j] : c32{ 0.0f, 0.0f };
-            float s1, c1, s2, c2;
-            sp_sincos(-cfo_c * (float)m, s1, c1);
-            sp_sincos((float)m * cfo_f, s2, c2);
-            v[j] = sp_rot(sp_rot(xs, s1, c1), s2, c2);
+            for (int j = 0; j < 4; j++) {
+                c32 xs = act ? cur[j] : c32{ 0.0f, 0.0f };
+                v[j] = sp_cmul(xs, w);
+                w = sp_cmul(w, u16);
+            }
         }
         // ---- FFT-64: three in-register radix-4 stages, two transposes through LDS ----
         bfly4_reg(v[0], v[1], v[2], v[3]);
@@ -391,17 +395,16 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         // stage-3 output q3 is sub-carrier k = r + 16 q3, i.e. shifted bin i = r + 16 ((q3 + 2) & 3)
         c32 X[4] = { v[2], v[3], v[0], v[1] };
 
-        // (1) sampling offset
+        // (1) sampling offset: bins (r - 32) + 16 j share the step exp(j t4 16/64)
         {
             double t4 = two_pi * s * 80 * (eps0 + d_er);
+            c32 step, q;
+            sp_sincos((float)(t4 * 16.0 / 64), step.im, step.re);
+            sp_sincos((float)(t4 * (double)(r - 32) / 64), q.im, q.re);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                int kk = r + 16 * j - 32;
-                asm volatile("" : "+v"(kk));
-                float ang = (float)(t4 * (double)kk / 64);
-                float sn, cs;
-                sp_sincos(ang, sn, cs);
-                X[j] = sp_rot(X[j], sn, cs);
+                X[j] = sp_cmul(X[j], q);
+                q = sp_cmul(q, step);
             }
         }
         // (2) pilots: bins 11, 25, 39, 53 = (lane 11, j 0), (lane 9, j 1), (lane 7, j 2), (lane 5, j 3)
@@ -458,7 +461,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 nv[j] = usedj ? fma_(d.im, d.im, d.re * d.re) : 0.0f;
                 sv[j] = usedj ? fma_(u.im, u.im, u.re * u.re) : 0.0f;
                 float g = 0.5f * WR_LTS_FREQ[i];
-                if (usedj) Hl[64 * j] = make_float2(u.re * g, u.im * g);
+                // G = conj(H)/|H|^2 replaces H in LDS: the one-tap equaliser as a multiplier
+                const float hr = u.re * g, hi = u.im * g, dd = fma_(hi, hi, hr * hr);
+                Hl[64 * j] = usedj ? make_float2(hr / dd, -hi / dd) : make_float2(0.0f, 0.0f);
                 // the spec's xor tree over the 64 bins: steps 1,2,4,8 inside the row ...
                 nv[j] = row_xor_sum16(nv[j]);
                 sv[j] = row_xor_sum16(sv[j]);
@@ -478,13 +483,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 asm volatile("" : "+v"(carrier[j]));     // keeps base + carrier out of loop-invariant registers
                 Y[j] = { 0.0f, 0.0f };
                 if (carrier[j] >= 0) {
-                    const float2 h0 = Hl[64 * j];
-                    float d = fma_(h0.y, h0.y, h0.x * h0.x);
-                    Y[j].re = fma_(X[j].im, h0.y, X[j].re * h0.x) / d;
-                    Y[j].im = fma_(X[j].im, h0.x, -(X[j].re * h0.y)) / d;
+                    const float2 g0 = Hl[64 * j];
+                    Y[j] = sp_cmul(X[j], c32{ g0.x, g0.y });
                 }
                 bits[j] = decide(Y[j], nb);
-                WR_SCHED_FENCE();       // one bin's two divisions at a time: the 8 interleaved need ~40 more VGPRs
             }
             if (s == 2) {
                 // (7) SIGNAL: per frame, gather the 48 decisions in carrier order, de-interleave, Viterbi

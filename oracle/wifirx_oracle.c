@@ -78,6 +78,30 @@ static inline void sp_sincos(float x, float* s, float* c)
     }
 }
 
+/* sine/cosine of a double angle: reduction by pi/2 in double (two fma with a hi/lo split), the
+ * polynomials of sp_sincos in float on the reduced argument */
+static inline void sp_sincos_d(double x, float* s, float* c)
+{
+    double kd = rint(x * WR_TWO_OVER_PI_D);
+    int    k  = (int)kd;
+    double rd = fma(-kd, WR_PIO2_D_HI, x);
+    rd = fma(-kd, WR_PIO2_D_LO, rd);
+    float r  = (float)rd;
+    float z  = r * r;
+    float ps = fmaf(z, WR_S3, WR_S2);
+    ps = fmaf(ps, z, WR_S1);
+    float sr = fmaf(ps * z, r, r);
+    float pc = fmaf(z, WR_C3, WR_C2);
+    pc = fmaf(pc, z, WR_C1);
+    float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    switch (k & 3) {
+    case 0:  *s = sr;  *c = cr;  break;
+    case 1:  *s = cr;  *c = -sr; break;
+    case 2:  *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr;  break;
+    }
+}
+
 static inline float sp_atan2(float y, float x)
 {
     float ax = fabsf(x), ay = fabsf(y);
@@ -615,9 +639,13 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     const double tag = (double)cfo_c - (double)cfo_f;          /* sync_long's wifi_start tag */
     const double eps0 = tag * bw / (2 * M_PI * fc);
     double d_er = 0.0;
+    const double theta_d = (double)cfo_f - (double)cfo_c;       /* total derotation, rad/sample */
+    c32 u16;                                                    /* exp(j theta 16) */
+    sp_sincos_d(theta_d * 16.0, &u16.im, &u16.re);
     c32 prev[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
-    c32 H[64];
+    c32 H[64], G[64];
     memset(H, 0, sizeof H);
+    memset(G, 0, sizeof G);
     int n_sym = 0, n_bpsc = 1, enc = 0, psdu_len = 0, have_signal = 0;
     int n_out = 0;
     float snr = 0.0f;
@@ -628,16 +656,27 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             fr->flags |= WIFIRX_F_TRUNCATED;
             break;
         }
-        /* sync_short copy + sync_long copy: two derotations per sample */
+        /* sync_short copy + sync_long copy.  Upstream: two float rotations exp(-j cfo_c m), exp(+j cfo_f m)
+         * per sample.  Spec (section 4.8): one rotation by the total offset; the phasor of sample m0 + r (r = 0..15)
+         * comes from a double angle reduced in double, the samples 16, 32, 48 further on from three
+         * multiplications by the frame's exp(j theta 16). */
         c32 z[64], X[64];
-        for (int i = 0; i < 64; i++) {
-            long m = off0 + i;
-            c32 xs = x_at(x, n_samp, t - 16 + m);
-            float a1 = -cfo_c * (float)m, a2 = (float)m * cfo_f, s1, c1, s2, c2;
-            if (spec) {
-                sp_sincos(a1, &s1, &c1); sp_sincos(a2, &s2, &c2);
-                z[i] = sp_rot(sp_rot(xs, s1, c1), s2, c2);
-            } else {
+        if (spec) {
+            for (int r = 0; r < 16; r++) {
+                float ws, wc;
+                sp_sincos_d(theta_d * (double)(off0 + r), &ws, &wc);
+                c32 w = { wc, ws };
+                for (int j = 0; j < 4; j++) {
+                    c32 xs = x_at(x, n_samp, t - 16 + off0 + r + 16 * j);
+                    z[r + 16 * j] = sp_cmul(xs, w);
+                    w = sp_cmul(w, u16);
+                }
+            }
+        } else {
+            for (int i = 0; i < 64; i++) {
+                long m = off0 + i;
+                c32 xs = x_at(x, n_samp, t - 16 + m);
+                float a1 = -cfo_c * (float)m, a2 = (float)m * cfo_f, s1, c1, s2, c2;
                 sincosf(a1, &s1, &c1); sincosf(a2, &s2, &c2);
                 float complex v = ((xs.re + I * xs.im) * (c1 + I * s1)) * (c2 + I * s2);
                 z[i].re = crealf(v); z[i].im = cimagf(v);
@@ -645,12 +684,24 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
         }
         if (spec) fft64_spec(z, X); else fft64_libm(z, X);
 
-        /* (1) sampling offset compensation */
+        /* (1) sampling offset compensation.  Spec: bins r-32 + 16 j share the step exp(j t4 16/64) */
         double t4 = 2 * M_PI * s * 80 * (eps0 + d_er);
-        for (int i = 0; i < 64; i++) {
-            float ang = (float)(t4 * (i - 32) / 64), sn, cs;
-            if (spec) { sp_sincos(ang, &sn, &cs); X[i] = sp_rot(X[i], sn, cs); }
-            else {
+        if (spec) {
+            float ss, sc;
+            sp_sincos((float)(t4 * 16.0 / 64), &ss, &sc);
+            c32 step = { sc, ss };
+            for (int r = 0; r < 16; r++) {
+                float bs, bc;
+                sp_sincos((float)(t4 * (double)(r - 32) / 64), &bs, &bc);
+                c32 q = { bc, bs };
+                for (int j = 0; j < 4; j++) {
+                    X[r + 16 * j] = sp_cmul(X[r + 16 * j], q);
+                    q = sp_cmul(q, step);
+                }
+            }
+        } else {
+            for (int i = 0; i < 64; i++) {
+                float ang = (float)(t4 * (i - 32) / 64), sn, cs;
                 sincosf(ang, &sn, &cs);
                 float complex v = (X[i].re + I * X[i].im) * (cs + I * sn);
                 X[i].re = crealf(v); X[i].im = cimagf(v);
@@ -721,6 +772,10 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                     sv[i] = fmaf(u.im, u.im, u.re * u.re);
                     float g = 0.5f * WR_LTS_FREQ[i];
                     H[i].re = u.re * g; H[i].im = u.im * g;
+                    /* G = conj(H)/|H|^2: the one-tap equaliser as a multiplier, two divisions per bin per frame */
+                    float dd = fmaf(H[i].im, H[i].im, H[i].re * H[i].re);
+                    G[i].re = H[i].re / dd;
+                    G[i].im = -H[i].im / dd;
                 }
                 snr = sp_snr_db(tree_sum64(sv), tree_sum64(nv));
             } else {
@@ -745,9 +800,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 if (i == 11 || i == 25 || i == 32 || i == 39 || i == 53 || i < 6 || i > 58) continue;
                 c32 yq;
                 if (spec) {
-                    float d = fmaf(H[i].im, H[i].im, H[i].re * H[i].re);
-                    yq.re = fmaf(X[i].im, H[i].im, X[i].re * H[i].re) / d;
-                    yq.im = fmaf(X[i].im, H[i].re, -(X[i].re * H[i].im)) / d;
+                    yq = sp_cmul(X[i], G[i]);
                 } else {
                     float complex v = (X[i].re + I * X[i].im) / (H[i].re + I * H[i].im);
                     yq.re = crealf(v); yq.im = cimagf(v);
