@@ -69,9 +69,12 @@ __device__ __forceinline__ float sp_atan2(float y, float x)
     float mn = ax > ay ? ay : ax;
     float a   = mn / mx;
     bool  big = a > WR_TAN_PIO8;
-    float num = big ? a - 1.0f : a;
-    float den = big ? a + 1.0f : 1.0f;
-    float t   = num / den;
+    float t   = a;                                  // a/1
+    if (__any(big)) {                               // wave-uniform: most calls see small angles only
+        float num = big ? a - 1.0f : a;
+        float den = big ? a + 1.0f : 1.0f;
+        t = num / den;
+    }
     float z   = t * t;
     float p   = fma_(z, WR_A4, WR_A3);
     p = fma_(p, z, WR_A2);

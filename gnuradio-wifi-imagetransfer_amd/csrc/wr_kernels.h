@@ -7,7 +7,7 @@
 
 #define WR_WAVES_PER_BLOCK 4
 #ifndef WR_DEMOD_WAVES_PER_SIMD
-#define WR_DEMOD_WAVES_PER_SIMD 3       // register budget of the demod kernels: 512/4 = 128 VGPRs
+#define WR_DEMOD_WAVES_PER_SIMD 4       // register budget of the demod kernels: 512/4 = 128 VGPRs
 #endif
 #define WR_YLDS_FLOATS     768      // 384 complex: the 383 coarse-derotated samples sync_long correlates
 #define WR_STREAM_SPAN     16       // tiles of 64 samples one wave scans in stream-mode detection

@@ -23,6 +23,10 @@
 #include "wr_kernels.h"
 #include "wr_quad.h"
 
+#ifndef WR_ABLATE
+#define WR_ABLATE 0
+#endif
+
 namespace wr {
 
 // ---------------------------------------------------------------------------------------------
@@ -157,6 +161,10 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
             seed.fs = fs; seed.flags = flags; seed.out = slot;
         }
     }
+#if WR_ABLATE == 1   // timing experiment: preamble phase only
+    if ((lane & 15) == 0 && seed.out >= 0) { frames[seed.out].flags = seed.flags; frames[seed.out].frame_start = seed.fs; frames[seed.out].cfo_fine = seed.cfo_f; frames[seed.out].trigger = (int)seed.t; }
+    return;
+#endif
     frames_quad(seed, prm, lds[wave], lane, frames, idx, llr, carrier);
 }
 

@@ -46,6 +46,17 @@ __device__ __forceinline__ c32 load_sample(const float2* __restrict__ x, long n,
     return z;
 }
 
+// y[m] of a frame, zero outside [m_lo, m_hi): branch-free (clamped address, selected value)
+__device__ __forceinline__ c32 load_y(const float2* __restrict__ xb, int m, int m_lo, int m_hi)
+{
+    int mc = m < m_hi - 1 ? m : m_hi - 1;
+    mc = mc > m_lo ? mc : m_lo;
+    const bool ok = (m >= m_lo) && (m < m_hi);
+    float2 t = make_float2(0.0f, 0.0f);
+    if (m_hi > m_lo) t = xb[mc];
+    return { ok ? t.x : 0.0f, ok ? t.y : 0.0f };
+}
+
 __device__ __forceinline__ uint8_t decide(c32 y, int n_bpsc)
 {
     float re = y.re, im = y.im, are = __builtin_fabsf(re), aim = __builtin_fabsf(im);
@@ -267,8 +278,17 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 {
     const int row = lane >> 4, r = lane & 15;
     // ---- row-uniform frame state, one copy per lane ----
-    const float2* x = seed.x;
-    const long  n_samp = seed.n_samp, t16 = seed.t - 16, L = seed.L, out = seed.out;
+    // Samples are addressed as xb[m], m = index into the copied stream y (xb = x + trigger - 16); m is valid
+    // for m_lo <= m < m_hi (the part of y that lies inside the slot / stream buffer).  Rows without a frame
+    // get an empty range on a harmless pointer.  32-bit indices: L <= 43200 + 320.
+    const bool  has = seed.out >= 0 && seed.x != nullptr && seed.t >= 0;
+    const long  t16 = seed.t - 16;
+    const float2* xb = has ? seed.x + t16 : reinterpret_cast<const float2*>(frames);
+    const int   m_lo = has ? (int)(t16 < 0 ? -t16 : 0) : 0;
+    const long  m_hi_l = seed.n_samp - t16;
+    const int   m_hi = has ? (int)(m_hi_l > 0x7fffff00l ? 0x7fffff00l : m_hi_l) : 0;
+    const int   L = (int)seed.L;
+    const long  out = seed.out;
     const float cfo_c = seed.cfo_c, cfo_f = seed.cfo_f;
     const int   fs = seed.fs;
     uint32_t flags = seed.flags;
@@ -325,10 +345,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     // is simply not used
     c32 nx[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) nx[j] = WR_PREFETCH ? load_sample(x, t16 + fs + r + 16 * j, n_samp) : c32{ 0.0f, 0.0f };
+    for (int j = 0; j < 4; j++) nx[j] = WR_PREFETCH ? load_y(xb, fs + r + 16 * j, m_lo, m_hi) : c32{ 0.0f, 0.0f };
 
     for (int s = 0;; s++) {
-        long off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
+        const int off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
         bool act = alive && (s <= n_sym + 2);
         if (act && (off0 + 64 > L || (s > 2 && (s - 3) >= (int)prm.max_sym))) {
             flags |= WIFIRX_F_TRUNCATED;
@@ -340,15 +360,15 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         // ---- samples r + 16 j of the symbol, two derotations each (sync_short / sync_long copy) ----
         c32 v[4], cur[4];
         {
-            const long offn = fs + (s + 1 < 2 ? 64 * (s + 1) : 128 + 80 * (s - 1) + 16);
+            const int offn = fs + (s + 1 < 2 ? 64 * (s + 1) : 128 + 80 * (s - 1) + 16);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
 #if WR_PREFETCH
                 cur[j] = nx[j];
-                nx[j] = load_sample(x, t16 + offn + r + 16 * j, n_samp);
+                nx[j] = load_y(xb, offn + r + 16 * j, m_lo, m_hi);
 #else
                 (void)offn;
-                cur[j] = act ? load_sample(x, t16 + off0 + r + 16 * j, n_samp) : c32{ 0.0f, 0.0f };
+                cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
 #endif
             }
         }
@@ -416,7 +436,6 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             S = csub(cadd(cadd(X11, X39), X25), X53);
             if (pneg) S = cneg(S);
         }
-        float beta = sp_atan2(S.im, S.re);
         // (3) residual offset estimate
         c32 cur0, cur1, cur2, cur3;
         if (s < 2) { cur0 = X11; cur1 = cneg(X25); cur2 = X39; cur3 = X53; }
@@ -433,10 +452,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             er = (double)sp_atan2(acc.im, acc.re) * er_scale;
         }
         prev0 = cur0; prev1 = cur1; prev2 = cur2; prev3 = cur3;
-        // (4) common phase
+        // (4) common phase: exp(-j beta) = conj(S)/|S| (spec section 4.9)
         {
-            float sn, cs;
-            sp_sincos(-beta, sn, cs);
+            float n2 = fma_(S.im, S.im, S.re * S.re);
+            float nn = __builtin_sqrtf(n2);
+            float cs = (nn > 0.0f) ? S.re / nn : 1.0f;
+            float sn = (nn > 0.0f) ? -S.im / nn : 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; j++) X[j] = sp_rot(X[j], sn, cs);
         }
@@ -562,7 +583,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         if (have_signal && n_out == n_sym) flags |= WIFIRX_F_COMPLETE;
         bool sync = (flags & WIFIRX_F_SYNC) != 0;
         fr.flags = flags;
-        fr.trigger = (int32_t)(t16 + 16);
+        fr.trigger = (int32_t)seed.t;
         fr.frame_start = sync ? fs : 0;
         fr.cfo_coarse = (flags & WIFIRX_F_DETECTED) ? cfo_c : 0.0f;
         fr.cfo_fine = sync ? cfo_f : 0.0f;

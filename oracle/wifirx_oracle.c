@@ -715,7 +715,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             S = csub(cadd(cadd(X[11], X[39]), X[25]), X[53]);
             if (p < 0) S = cneg(S);
         }
-        float beta = spec ? sp_atan2(S.im, S.re) : atan2f(S.im, S.re);
+        float beta = spec ? 0.0f : atan2f(S.im, S.re);    /* the spec never forms beta itself */
         /* (3) residual frequency offset from pilot rotation between symbols */
         c32 cur[4];
         if (s < 2) { cur[0] = X[11]; cur[1] = cneg(X[25]); cur[2] = X[39]; cur[3] = X[53]; }
@@ -741,10 +741,18 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             er = (double)erf * (bw / (2 * M_PI * fc * 80));
         }
         memcpy(prev, cur, sizeof prev);
-        /* (4) derotate by -beta */
+        /* (4) derotate by -beta.  Spec (section 4.9): exp(-j beta) = conj(S)/|S| with a correctly rounded sqrt and two
+         * divisions, no atan2/sincos round trip; S = 0 rotates by 0 like arg(0) = 0. */
         {
             float sn, cs;
-            if (spec) sp_sincos(-beta, &sn, &cs); else sincosf(-beta, &sn, &cs);
+            if (spec) {
+                float n2 = fmaf(S.im, S.im, S.re * S.re);
+                float nn = sqrtf(n2);
+                cs = (nn > 0.0f) ? S.re / nn : 1.0f;
+                sn = (nn > 0.0f) ? -S.im / nn : 0.0f;
+            } else {
+                sincosf(-beta, &sn, &cs);
+            }
             for (int i = 0; i < 64; i++) {
                 if (spec) X[i] = sp_rot(X[i], sn, cs);
                 else {
