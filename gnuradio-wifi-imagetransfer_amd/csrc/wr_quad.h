@@ -33,7 +33,8 @@ namespace wr {
 #define WR_QLDS_SCRATCH 768
 #define WR_QLDS_H       (WR_QLDS_SCRATCH)            // 4 x 64 float2: channel estimate, lane-private slots
 #define WR_QLDS_TW      (WR_QLDS_H + 512)              // 6 x 16 float2: stage-1/2 twiddles by row lane
-#define WR_QLDS_FLOATS  (WR_QLDS_TW + 192)          // per wave: max(383 preamble samples, 4 rows x 64 values) complex
+#define WR_QLDS_PREV    (WR_QLDS_TW + 192)             // 4 rows x 4 float2: pilots of the previous symbol
+#define WR_QLDS_FLOATS  (WR_QLDS_PREV + 32)          // per wave: max(383 preamble samples, 4 rows x 64 values) complex
 
 __device__ __forceinline__ c32 load_sample(const float2* __restrict__ x, long n, long n_samp)
 {
@@ -76,22 +77,24 @@ __device__ __forceinline__ uint8_t decide(c32 y, int n_bpsc)
 
 // Viterbi over the 24 SIGNAL bits, lane <-> state.  cbits: the 48 de-interleaved hard decisions
 // (bit j = coded bit j).  Returns the 24 decoded bits (bit t = decoded bit t), wave-uniform.
-__device__ __forceinline__ uint32_t viterbi_signal(uint64_t cbits, int lane)
+// The 24 survivor words go through `scr` (24 x 8 B of wave-private LDS): held in SGPRs they would push
+// the kernel's constants out of the scalar register file for the whole symbol loop.
+__device__ __forceinline__ uint32_t viterbi_signal(uint64_t cbits, int lane, uint64_t* scr)
 {
     const int s = lane, u = s & 1, p0 = s >> 1, p1 = (s >> 1) | 32;
     const int f0 = (p0 << 1) | u, f1 = (p1 << 1) | u;
     const int a0 = __builtin_popcount(f0 & 0155) & 1, b0 = __builtin_popcount(f0 & 0117) & 1;
     const int a1 = __builtin_popcount(f1 & 0155) & 1, b1 = __builtin_popcount(f1 & 0117) & 1;
     int pm = (s == 0) ? 0 : (1 << 24);
-    uint64_t dec[24];
-#pragma unroll
+#pragma unroll 1
     for (int t = 0; t < 24; t++) {
         int ra = (int)((cbits >> (2 * t)) & 1), rb = (int)((cbits >> (2 * t + 1)) & 1);
         int m0 = __shfl(pm, p0, 64) + (ra != a0) + (rb != b0);
         int m1 = __shfl(pm, p1, 64) + (ra != a1) + (rb != b1);
         bool sel = m1 < m0;
         pm = sel ? m1 : m0;
-        dec[t] = __ballot(sel);
+        uint64_t d = __ballot(sel);
+        if (lane == 0) scr[t] = d;
     }
     int key = (pm << 6) | s;      // best final state: smallest metric, lowest index on ties
 #pragma unroll
@@ -100,13 +103,19 @@ __device__ __forceinline__ uint32_t viterbi_signal(uint64_t cbits, int lane)
         key = o < key ? o : key;
     }
     int st = key & 63;
+    __builtin_amdgcn_wave_barrier();
+    uint64_t mine = (lane < 24) ? scr[lane] : 0;      // lane t holds survivor word t
+    uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
     uint32_t bits = 0;
-#pragma unroll
+#pragma unroll 1
     for (int t = 23; t >= 0; t--) {
         bits |= (uint32_t)(st & 1) << t;
-        int h = (int)((dec[t] >> st) & 1);
-        st = (st >> 1) | (h << 5);
+        uint32_t dlo = (uint32_t)__builtin_amdgcn_readlane((int)lo, t);
+        uint32_t dhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, t);
+        uint32_t h = (st < 32 ? (dlo >> st) : (dhi >> (st - 32))) & 1u;
+        st = (st >> 1) | (int)(h << 5);
     }
+    __builtin_amdgcn_wave_barrier();
     return bits;
 }
 
@@ -288,7 +297,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     const long  m_hi_l = seed.n_samp - t16;
     const int   m_hi = has ? (int)(m_hi_l > 0x7fffff00l ? 0x7fffff00l : m_hi_l) : 0;
     const int   L = (int)seed.L;
-    const long  out = seed.out;
+    const int   out = (int)seed.out;
+    const int   trig = (int)seed.t;
     const float cfo_c = seed.cfo_c, cfo_f = seed.cfo_f;
     const int   fs = seed.fs;
     uint32_t flags = seed.flags;
@@ -302,7 +312,6 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     const double theta_d = (double)cfo_f - (double)cfo_c;      // total derotation, rad/sample
     c32 u16;                                                   // exp(j theta 16)
     sp_sincos_d(theta_d * 16.0, u16.im, u16.re);
-    c32 prev0 = { 0, 0 }, prev1 = { 0, 0 }, prev2 = { 0, 0 }, prev3 = { 0, 0 };
     int n_sym = 0, n_bpsc = 1, n_out = 0, enc = 0, psdu_len = 0;
     bool have_signal = false, want_llr = false;
     float snr = 0.0f;
@@ -319,6 +328,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         }
     }
     float2* Hl = reinterpret_cast<float2*>(qlds + WR_QLDS_H) + lane;      // element j at Hl[64 j]
+    float2* pvl = reinterpret_cast<float2*>(qlds + WR_QLDS_PREV) + 4 * row;
     int carrier0[4];                     // data carrier number 0..47 of bin r + 16 j, -1 for pilots / DC / guards
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -336,9 +346,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     // transpose A: stage-1 output q of lane r=(m, c) is element (q, m, c); lane (q1=c2, m) reads (q1, m, j)
     // transpose B: stage-2 output q2 of lane (q1=c2, m) is element (q2, q1, m); lane (q1=r&3, q2=c2) reads (q2, q1, j)
     const size_t per = (size_t)prm.max_sym * 48;
-    uint8_t* idx = (idx_all && out >= 0) ? idx_all + out * per : nullptr;
-    float*   llr = (llr_all && out >= 0) ? llr_all + out * per * prm.llr_bits : nullptr;
-    float2*  car = (car_all && out >= 0) ? car_all + out * per : nullptr;
+    uint8_t* idx = (idx_all && out >= 0) ? idx_all + (size_t)out * per : nullptr;
+    float*   llr = (llr_all && out >= 0) ? llr_all + (size_t)out * per * prm.llr_bits : nullptr;
+    float2*  car = (car_all && out >= 0) ? car_all + (size_t)out * per : nullptr;
 
     // samples of symbol 0, then always one symbol ahead of the arithmetic (hides the HBM latency that
     // 2-4 waves per SIMD cannot); loads are bounds-checked only, a symbol that turns out not to exist
@@ -447,11 +457,18 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         }
         double er = 0.0;
         if (s >= 2) {
+            const float2 q0 = pvl[0], q1 = pvl[1], q2 = pvl[2], q3 = pvl[3];
+            const c32 prev0 = { q0.x, q0.y }, prev1 = { q1.x, q1.y }, prev2 = { q2.x, q2.y }, prev3 = { q3.x, q3.y };
             c32 acc = cadd(cadd(cadd(sp_conj_mul(prev0, cur0), sp_conj_mul(prev1, cur1)),
                                 sp_conj_mul(prev2, cur2)), sp_conj_mul(prev3, cur3));
             er = (double)sp_atan2(acc.im, acc.re) * er_scale;
         }
-        prev0 = cur0; prev1 = cur1; prev2 = cur2; prev3 = cur3;
+        __builtin_amdgcn_wave_barrier();
+        if (r == 0) {
+            pvl[0] = make_float2(cur0.re, cur0.im); pvl[1] = make_float2(cur1.re, cur1.im);
+            pvl[2] = make_float2(cur2.re, cur2.im); pvl[3] = make_float2(cur3.re, cur3.im);
+        }
+        __builtin_amdgcn_wave_barrier();
         // (4) common phase: exp(-j beta) = conj(S)/|S| (spec section 4.9)
         {
             float n2 = fma_(S.im, S.im, S.re * S.re);
@@ -515,7 +532,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #pragma unroll
                 for (int j = 0; j < 4; j++) bal[j] = __ballot(carrier[j] >= 0 && (bits[j] & 1));
                 const uint64_t actmask = __ballot(act);
-#pragma unroll
+#pragma unroll 1
                 for (int f = 0; f < 4; f++) {
                     if (!((actmask >> (16 * f)) & 1)) continue;
                     uint64_t b = 0;
@@ -525,9 +542,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                                   (((b >> 26) & 0x3full) << 18) | (((b >> 33) & 0x3full) << 24) |
                                   (((b >> 40) & 0x1fffull) << 30) | (((b >> 54) & 0x1full) << 43);
                     uint64_t de = 0;
-#pragma unroll
+#pragma unroll 1
                     for (int jj = 0; jj < 48; jj++) de |= ((cm >> (3 * (jj % 16) + jj / 16)) & 1ull) << jj;
-                    uint32_t sig = viterbi_signal(de, lane);
+                    uint32_t sig = viterbi_signal(de, lane, reinterpret_cast<uint64_t*>(qlds));
                     int e = 0, len = 0;
                     bool ok = parse_signal(sig, e, len);
                     if (row == f) {
@@ -583,7 +600,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         if (have_signal && n_out == n_sym) flags |= WIFIRX_F_COMPLETE;
         bool sync = (flags & WIFIRX_F_SYNC) != 0;
         fr.flags = flags;
-        fr.trigger = (int32_t)seed.t;
+        fr.trigger = trig;
         fr.frame_start = sync ? fs : 0;
         fr.cfo_coarse = (flags & WIFIRX_F_DETECTED) ? cfo_c : 0.0f;
         fr.cfo_fine = sync ? cfo_f : 0.0f;
