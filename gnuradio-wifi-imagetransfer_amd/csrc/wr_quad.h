@@ -279,6 +279,38 @@ __device__ __forceinline__ float row_xor_sum16(float v)
     return v;
 }
 
+// a6 + a7 stores of one lane's four bins for constellation NB (compile-time: no per-lane branching on it).
+// ok = row active; the pointers are the row's output slices.
+template <int NB>
+__device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrier)[4], bool ok, int q,
+                                           uint8_t* __restrict__ idx, float2* __restrict__ car,
+                                           float* __restrict__ llr, bool has_idx, bool has_car, bool want_llr)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!(ok && carrier[j] >= 0)) continue;
+        const unsigned o = (unsigned)(q * 48 + carrier[j]);
+        if (has_idx) idx[o] = decide(Y[j], NB);
+        if (has_car) car[o] = make_float2(Y[j].re, Y[j].im);
+        if (want_llr) {
+            const float are = __builtin_fabsf(Y[j].re), aim = __builtin_fabsf(Y[j].im);
+            float* lp = llr + (size_t)o * NB;
+            if (NB == 1) {
+                lp[0] = Y[j].re;
+            } else if (NB == 2) {
+                *reinterpret_cast<float2*>(lp) = make_float2(Y[j].re, Y[j].im);
+            } else if (NB == 4) {
+                *reinterpret_cast<float4*>(lp) = make_float4(Y[j].re, WR_T16_2 - are, Y[j].im, WR_T16_2 - aim);
+            } else {
+                float2* l2 = reinterpret_cast<float2*>(lp);
+                l2[0] = make_float2(Y[j].re, WR_T64_4 - are);
+                l2[1] = make_float2(WR_T64_2 - __builtin_fabsf(are - WR_T64_4), Y[j].im);
+                l2[2] = make_float2(WR_T64_4 - aim, WR_T64_2 - __builtin_fabsf(aim - WR_T64_4));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // a3 copy + a4 + a5 + a6 + a7 for the four frames of a wave.
 __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodParams& prm, float* qlds, int lane,
@@ -511,9 +543,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             float noise = n01 + n23, signal = s01 + s23;
             if (act) snr = sp_snr_db(signal, noise);
         } else {
-            int nb = (s == 2) ? 1 : n_bpsc;
             c32 Y[4];
-            uint8_t bits[4];
             int carrier[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -524,13 +554,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                     const float2 g0 = Hl[64 * j];
                     Y[j] = sp_cmul(X[j], c32{ g0.x, g0.y });
                 }
-                bits[j] = decide(Y[j], nb);
             }
             if (s == 2) {
-                // (7) SIGNAL: per frame, gather the 48 decisions in carrier order, de-interleave, Viterbi
+                // (7) SIGNAL: per frame, gather the 48 BPSK decisions in carrier order, de-interleave, Viterbi
                 uint64_t bal[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) bal[j] = __ballot(carrier[j] >= 0 && (bits[j] & 1));
+                for (int j = 0; j < 4; j++) bal[j] = __ballot(carrier[j] >= 0 && Y[j].re > 0.0f);
                 const uint64_t actmask = __ballot(act);
 #pragma unroll 1
                 for (int f = 0; f < 4; f++) {
@@ -565,33 +594,25 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                         }
                     }
                 }
-            } else if (act) {
-                // (8) data symbol q
-                int q = s - 3;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (carrier[j] < 0) continue;
-                    size_t o = (size_t)q * 48 + carrier[j];
-                    if (idx) idx[o] = bits[j];
-                    if (car) car[o] = make_float2(Y[j].re, Y[j].im);
-                    if (want_llr) {
-                        float are = __builtin_fabsf(Y[j].re), aim = __builtin_fabsf(Y[j].im);
-                        float* lp = llr + o * n_bpsc;
-                        if (n_bpsc == 1) {
-                            lp[0] = Y[j].re;
-                        } else if (n_bpsc == 2) {
-                            *reinterpret_cast<float2*>(lp) = make_float2(Y[j].re, Y[j].im);
-                        } else if (n_bpsc == 4) {
-                            *reinterpret_cast<float4*>(lp) = make_float4(Y[j].re, WR_T16_2 - are, Y[j].im, WR_T16_2 - aim);
-                        } else {
-                            float2* l2 = reinterpret_cast<float2*>(lp);
-                            l2[0] = make_float2(Y[j].re, WR_T64_4 - are);
-                            l2[1] = make_float2(WR_T64_2 - __builtin_fabsf(are - WR_T64_4), Y[j].im);
-                            l2[2] = make_float2(WR_T64_4 - aim, WR_T64_2 - __builtin_fabsf(aim - WR_T64_4));
-                        }
-                    }
+            } else {
+                // (8) data symbol q.  The constellation is usually the same in all active rows: then the slicer and
+                // the LLR stores are picked by one scalar branch; mixed rows take the per-constellation passes.
+                const int q = s - 3;
+                const bool has_idx = idx_all != nullptr, has_car = car_all != nullptr;
+                const int nbu = __builtin_amdgcn_readfirstlane(n_bpsc);      // the loop ran: some lane is active, but
+                const bool uniform = __all(!act || n_bpsc == nbu) && __builtin_amdgcn_readfirstlane((int)act);
+                if (uniform) {
+                    if (nbu == 1)      store_bins<1>(Y, carrier, act, q, idx, car, llr, has_idx, has_car, want_llr);
+                    else if (nbu == 2) store_bins<2>(Y, carrier, act, q, idx, car, llr, has_idx, has_car, want_llr);
+                    else if (nbu == 4) store_bins<4>(Y, carrier, act, q, idx, car, llr, has_idx, has_car, want_llr);
+                    else               store_bins<6>(Y, carrier, act, q, idx, car, llr, has_idx, has_car, want_llr);
+                } else {
+                    store_bins<1>(Y, carrier, act && n_bpsc == 1, q, idx, car, llr, has_idx, has_car, want_llr);
+                    store_bins<2>(Y, carrier, act && n_bpsc == 2, q, idx, car, llr, has_idx, has_car, want_llr);
+                    store_bins<4>(Y, carrier, act && n_bpsc == 4, q, idx, car, llr, has_idx, has_car, want_llr);
+                    store_bins<6>(Y, carrier, act && n_bpsc == 6, q, idx, car, llr, has_idx, has_car, want_llr);
                 }
-                n_out = q + 1;
+                if (act) n_out = q + 1;
             }
         }
     }
