@@ -44,7 +44,8 @@ struct wifirx_handle {
     void*  stage_psdu = nullptr;    size_t stage_psdu_bytes = 0;
 
     // decode workspace
-    void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;  size_t dec_scratch_stride = 0;
+    void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;
+    void*  dec_max = nullptr;       size_t dec_max_bytes = 0;
 
     // stream mode
     float2*  sbuf = nullptr;        int64_t sbuf_cap = 0;     // device sample buffer
@@ -144,7 +145,7 @@ int wifirx_destroy(wifirx_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu,
-                     h->dec_scratch, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx, h->s_llr,
+                     h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx, h->s_llr,
                      h->s_car, h->s_psdu };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->stream) (void)hipStreamDestroy(h->stream);

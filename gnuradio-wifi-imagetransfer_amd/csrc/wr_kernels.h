@@ -11,7 +11,8 @@
 #endif
 #define WR_YLDS_FLOATS     768      // 384 complex: the 383 coarse-derotated samples sync_long correlates
 #define WR_STREAM_SPAN     16       // tiles of 64 samples one wave scans in stream-mode detection
-#define WR_DECODE_MAX_WAVES 8192    // resident waves of the decode kernel (each owns a scratch slice)
+#define WR_DECODE_MAX_WAVES 4096    // waves of the decode kernel (64 frames each, grid-stride; each owns a scratch slice)
+#define WR_DECODE_SCRATCH_BUDGET (16ull << 30)   // bytes of survivor scratch a decode call may hold
 
 namespace wr {
 
@@ -41,9 +42,11 @@ hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot
 hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_templates, uint32_t frame_len,
                            float2* slots, uint32_t slot_len, uint32_t n_slots, uint32_t lead, float gain,
                            float cfo_max, uint64_t seed, float* cfo_out);
+hipError_t wr_launch_decode_maxsteps(hipStream_t st, uint32_t n_slots, uint32_t max_sym,
+                                     const wifirx_frame* frames, uint32_t psdu_stride, uint32_t* out);
 hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                             const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
-                            size_t scratch_stride);
+                            size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves);
 hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_samp, int64_t tile0,
                                    int64_t n_tiles, float thr, uint64_t* masks, float2* A);
 hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
