@@ -25,17 +25,27 @@
 
 namespace wr {
 
+#ifndef WR_DEC_ASM
+#define WR_DEC_ASM 1
+#endif
+#ifndef WR_DEC_WAVES_PER_SIMD
+#define WR_DEC_WAVES_PER_SIMD 4
+#endif
 #define WR_DEC_CHUNK      60                   // trellis steps per gathered mask word (10 groups of 6)
 #define WR_DEC_SEG_CHUNKS 4                    // chunks gathered per segment: 240 steps (8 KB of LDS per wave)
 #define WR_DEC_LDS_WORDS  (WR_DEC_SEG_CHUNKS * 4 * 64)   // per wave, 8-byte words: [chunk][A1,AV,B1,BV][frame]
 
-// the coded bit at position `ci` of the de-punctured stream of a frame: 0/1, or 2 when punctured
-__device__ __forceinline__ int coded_bit(const uint8_t* __restrict__ idx, int ci, int punct, int n_bpsc, int n_cbps)
+// the coded bit at position `ci` of the de-punctured stream of a frame: 0/1, or 2 when punctured.
+// Rate parameters are template constants: every division below is by a compile-time constant.
+template <int PUNCT, int N_BPSC>
+__device__ __forceinline__ int coded_bit(const uint8_t* __restrict__ idx, int ci)
 {
+    constexpr int n_cbps = 48 * N_BPSC;
+    constexpr int s = (N_BPSC / 2) < 1 ? 1 : (N_BPSC / 2);
     int pidx;
-    if (punct == 0) {
+    if (PUNCT == 0) {
         pidx = ci;
-    } else if (punct == 1) {               // 2/3: every 4th bit dropped
+    } else if (PUNCT == 1) {               // 2/3: every 4th bit dropped
         int r = ci & 3;
         if (r == 3) return 2;
         pidx = (ci >> 2) * 3 + r;
@@ -45,11 +55,24 @@ __device__ __forceinline__ int coded_bit(const uint8_t* __restrict__ idx, int ci
         pidx = g * 4 + (r < 3 ? r : 3);
     }
     int sym = pidx / n_cbps, k = pidx - sym * n_cbps;
-    int s = n_bpsc >> 1; if (s < 1) s = 1;
     int i = (n_cbps >> 4) * (k & 15) + (k >> 4);
     int j = s * (i / s) + (i + n_cbps - (16 * i) / n_cbps) % s;
-    int carrier = j / n_bpsc, bit = j - carrier * n_bpsc;
+    int carrier = j / N_BPSC, bit = j - carrier * N_BPSC;
     return (idx[sym * 48 + carrier] >> bit) & 1;
+}
+
+// gathers one chunk (lane <-> step t0 + lane) of one frame into the four mask words
+template <int PUNCT, int N_BPSC>
+__device__ __forceinline__ void gather_chunk(const uint8_t* __restrict__ fidx, int t, bool in_range,
+                                             uint64_t& A1, uint64_t& AV, uint64_t& B1, uint64_t& BV)
+{
+    int ra = 2, rb = 2;
+    if (in_range) {
+        ra = coded_bit<PUNCT, N_BPSC>(fidx, 2 * t);
+        rb = coded_bit<PUNCT, N_BPSC>(fidx, 2 * t + 1);
+    }
+    A1 = __ballot(ra == 1); AV = __ballot(ra != 2);
+    B1 = __ballot(rb == 1); BV = __ballot(rb != 2);
 }
 
 constexpr __host__ __device__ int rotr6(int s, int p) { return ((s >> p) | (s << (6 - p))) & 63; }
@@ -58,16 +81,22 @@ constexpr __host__ __device__ int parity_of(int v) { return __builtin_popcount(v
 // new = min(c0, c1), decision = (c1 < c0) shifted into `word` (word = 2*word + decision)
 __device__ __forceinline__ int acs_one(int c0, int c1, uint32_t& word)
 {
+#if WR_DEC_ASM
     uint32_t w = word;
     int m;
-    asm volatile("v_cmp_lt_i32 vcc, %3, %4\n\t"
-                 "v_cndmask_b32 %0, %4, %3, vcc\n\t"
-                 "v_addc_co_u32 %1, vcc, %2, %2, vcc"
-                 : "=&v"(m), "=v"(w)
-                 : "v"(w), "v"(c1), "v"(c0)
-                 : "vcc");
+    uint64_t cc;
+    asm("v_cmp_lt_i32 %2, %4, %5\n\t"
+        "v_cndmask_b32 %0, %5, %4, %2\n\t"
+        "v_addc_co_u32 %1, %2, %3, %3, %2"
+        : "=&v"(m), "=v"(w), "=&s"(cc)
+        : "v"(w), "v"(c1), "v"(c0));
     word = w;
     return m;
+#else
+    const bool d = c1 < c0;
+    word = word + word + (uint32_t)d;
+    return d ? c1 : c0;
+#endif
 }
 
 // one trellis step at register phase P: logical state s lives in pm[rotr6(s, P)].
@@ -75,6 +104,7 @@ __device__ __forceinline__ int acs_one(int c0, int c1, uint32_t& word)
 template <int P>
 __device__ __forceinline__ void acs_step(int (&pm)[64], const int (&M)[2][2], uint32_t& dlo, uint32_t& dhi)
 {
+    uint32_t acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // acc[k]: states 8k..8k+7, first state in the top bit
     // logical order 0..63 so that the survivor bit of state s ends at bit (31 - s%32) of dlo (s<32) / dhi
 #pragma unroll
     for (int j = 0; j < 32; j++) {
@@ -83,13 +113,15 @@ __device__ __forceinline__ void acs_step(int (&pm)[64], const int (&M)[2][2], ui
         const int m = M[a][b], mb = M[a ^ 1][b ^ 1];
         const int r0 = rotr6(j, P), r1 = rotr6(j + 32, P);
         const int p0 = pm[r0], p1 = pm[r1];
-        uint32_t& w = (j < 16) ? dlo : dhi;
+        uint32_t& w = acc[j >> 2];
         // state 2j (input bit 0): from j with m, from j+32 with mb;  state 2j+1: metrics swapped
         const int n0 = acs_one(p0 + m, p1 + mb, w);
         const int n1 = acs_one(p0 + mb, p1 + m, w);
         pm[r0] = n0;      // = register of logical state 2j at phase P+1
         pm[r1] = n1;      // = register of logical state 2j+1 at phase P+1
     }
+    dlo = (acc[0] << 24) | (acc[1] << 16) | (acc[2] << 8) | acc[3];
+    dhi = (acc[4] << 24) | (acc[5] << 16) | (acc[6] << 8) | acc[7];
 }
 
 __device__ __forceinline__ uint32_t crc32_bit(uint32_t c, uint32_t bit)
@@ -98,7 +130,7 @@ __device__ __forceinline__ uint32_t crc32_bit(uint32_t c, uint32_t bit)
     return (c >> 1) ^ (0xedb88320u & (0u - x));
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, WR_DEC_WAVES_PER_SIMD)
 void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
                    const uint8_t* __restrict__ idx_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
                    uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total)
@@ -113,9 +145,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
     uint64_t* surv = reinterpret_cast<uint64_t*>(scratch + (size_t)wave * scratch_stride);   // [step][lane]
     uint32_t* dbits = reinterpret_cast<uint32_t*>(surv + n_data_cap * 64);                   // [word][lane]
 
-    const int nbpsc_tab[8] = { 1, 1, 2, 2, 4, 4, 6, 6 };
     const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
-    const int punct_tab[8] = { 0, 2, 0, 2, 0, 2, 1, 2 };
 
     for (uint32_t base = wave * 64; base < n_slots; base += n_waves_total * 64) {
         // ---- my frame ----
@@ -153,19 +183,23 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                 const int f_enc = __builtin_amdgcn_readlane(enc, f);
                 const int f_ndata = __builtin_amdgcn_readlane(n_data, f);
                 if (seg0 >= f_ndata) continue;
-                const int f_bpsc = nbpsc_tab[f_enc], f_punct = punct_tab[f_enc], f_cbps = 48 * f_bpsc;
                 const uint8_t* fidx = idx_all + (size_t)(base + f) * max_sym * 48;
                 for (int c = 0; c < WR_DEC_SEG_CHUNKS; c++) {
                     const int t0 = seg0 + c * WR_DEC_CHUNK;
                     if (t0 >= f_ndata) break;
                     const int t = t0 + lane;
-                    int ra = 2, rb = 2;
-                    if (lane < WR_DEC_CHUNK && t < f_ndata) {
-                        ra = coded_bit(fidx, 2 * t, f_punct, f_bpsc, f_cbps);
-                        rb = coded_bit(fidx, 2 * t + 1, f_punct, f_bpsc, f_cbps);
+                    const bool in_range = lane < WR_DEC_CHUNK && t < f_ndata;
+                    uint64_t A1, AV, B1, BV;
+                    switch (f_enc) {
+                    case 0:  gather_chunk<0, 1>(fidx, t, in_range, A1, AV, B1, BV); break;
+                    case 1:  gather_chunk<2, 1>(fidx, t, in_range, A1, AV, B1, BV); break;
+                    case 2:  gather_chunk<0, 2>(fidx, t, in_range, A1, AV, B1, BV); break;
+                    case 3:  gather_chunk<2, 2>(fidx, t, in_range, A1, AV, B1, BV); break;
+                    case 4:  gather_chunk<0, 4>(fidx, t, in_range, A1, AV, B1, BV); break;
+                    case 5:  gather_chunk<2, 4>(fidx, t, in_range, A1, AV, B1, BV); break;
+                    case 6:  gather_chunk<1, 6>(fidx, t, in_range, A1, AV, B1, BV); break;
+                    default: gather_chunk<2, 6>(fidx, t, in_range, A1, AV, B1, BV); break;
                     }
-                    const uint64_t A1 = __ballot(ra == 1), AV = __ballot(ra != 2);
-                    const uint64_t B1 = __ballot(rb == 1), BV = __ballot(rb != 2);
                     if (lane < 4) {
                         uint64_t wsel = lane == 0 ? A1 : lane == 1 ? AV : lane == 2 ? B1 : BV;
                         lds[(c * 4 + lane) * 64 + f] = wsel;
