@@ -8,8 +8,10 @@ LS equalise + hard demap + LLR, one fused HIP kernel) over one device-resident b
 synthetic 802.11a frames: BASELINE.json configs[1] = 1,000,000 QPSK-1/2 frames of 294-byte
 PSDUs at 20 MHz, AWGN SNR 20 dB, per-frame CFO within +-20 ppm, one frame per 4608-sample slot.
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns its own
-1M-frame shard (weak scaling); a step then also runs decode_mac on the device and all-gathers the
-decoded PDUs over RCCL, which is the only exchange the path has.
+1M-frame shard (weak scaling); the hot path has no exchange step, so the timed region is the same
+at every N.  What follows the hot path -- decode_mac on the device and, for N > 1, the RCCL
+all-gather that reassembles the decoded PDU stream on every rank -- is run and timed separately
+after the timed region and reported in the extra object "pdu_leg" (never part of `value`).
 
 Rank 0 prints ONE JSON line (see the round prompt for the contract) with the extra objects
 "roofline" (dominant kernel, algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak)
@@ -54,7 +56,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (config 2: 1M)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="target wall time of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--decode", action="store_true", help="also run decode_mac in every step at N=1")
+    ap.add_argument("--decode", action="store_true", help="put decode_mac (and the all-gather) INSIDE every timed step")
+    ap.add_argument("--pdu-steps", type=int, default=2, help="steps of the separate decode_mac + all-gather leg (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,7 +83,8 @@ def main():
     n_frames = args.frames
     n_sym = txgen.n_sym_for(PSDU_LEN, ENCODING)
     n_bpsc = txgen.RATE_TABLE[ENCODING][0]
-    do_decode = args.decode or world > 1
+    do_decode = args.decode                 # decode inside the timed step (off by default)
+    want_pdus = do_decode or args.pdu_steps > 0
 
     # ---- synthetic input: host templates -> device slots (Philox AWGN + CFO on the GPU) ----
     psdu = txgen.make_psdus(N_TEMPLATES, PSDU_LEN, seed=2025 + rank)
@@ -99,20 +103,28 @@ def main():
     idx_t = torch.zeros((n_frames, n_sym * 48), dtype=torch.uint8, device="cuda")
     llr_t = torch.zeros((n_frames, n_sym * 48 * n_bpsc), dtype=torch.float32, device="cuda")
     psdu_stride = 320
-    psdu_t = torch.zeros((n_frames, psdu_stride), dtype=torch.uint8, device="cuda") if do_decode else None
+    psdu_t = torch.zeros((n_frames, psdu_stride), dtype=torch.uint8, device="cuda") if want_pdus else None
     out = capi.Out(frames_t.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), None,
-                   psdu_t.data_ptr() if do_decode else None, psdu_stride if do_decode else 0, 1)
+                   psdu_t.data_ptr() if want_pdus else None, psdu_stride if want_pdus else 0, 1)
     def step():
         """one pass of the hot path; returns the demod kernel's HIP-event time in ms"""
         ms = capi.C.c_float(0)
         rx._check(capi.lib().wifirx_time_demod(rx._h, iq.data_ptr(), SLOT_LEN, n_frames, capi.C.byref(out), 1,
                                                capi.C.byref(ms)))
         if do_decode:
-            rx._check(capi.lib().wifirx_decode_batch(rx._h, n_frames, capi.C.byref(out)))
-            rx.sync()
-            if world > 1:
-                wdist.all_gather_pdus(psdu_t, frames_t)
+            pdu_step()
         return ms.value
+
+    def pdu_step():
+        """decode_mac over the demodulated batch (+ all-gather of PSDUs and frame records for N > 1)"""
+        t_a = time.perf_counter()
+        rx._check(capi.lib().wifirx_decode_batch(rx._h, n_frames, capi.C.byref(out)))
+        rx.sync()
+        t_b = time.perf_counter()
+        if world > 1:
+            wdist.all_gather_pdus(psdu_t, frames_t)
+            torch.cuda.synchronize()
+        return (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3
 
     def barrier():
         if world > 1:
@@ -138,14 +150,41 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     kernel_ms_avg = kernel_ms / args.steps
 
+    # ---- the leg behind the hot path: decode_mac (+ RCCL all-gather of the PDUs), timed on its own ----
+    pdu_leg = None
+    if args.pdu_steps > 0:
+        barrier()
+        dec_ms, ag_ms = [], []
+        t1 = time.perf_counter()
+        for _ in range(args.pdu_steps):
+            d, a = pdu_step()
+            dec_ms.append(d)
+            ag_ms.append(a)
+        barrier()
+        leg = (time.perf_counter() - t1) / args.pdu_steps * 1e3
+        pdu_leg = {"decode_mac_ms": float(np.median(dec_ms)), "all_gather_ms": float(np.median(ag_ms)) if world > 1 else None,
+                   "ms_per_step": leg, "psdu_stride": psdu_stride,
+                   "note": "decode_mac on the device + RCCL all_gather_into_tensor of PSDUs and frame records; not in `value`"}
+
     # ---- sanity of the timed work: every frame must have been demodulated completely ----
     fr = frames_t.cpu().numpy().view(capi.FRAME_DTYPE).reshape(-1)
     n_complete = int(((fr["flags"] & capi.F_COMPLETE) != 0).sum())
-    n_crc = int(((fr["flags"] & capi.F_CRC_OK) != 0).sum()) if do_decode else None
+    n_crc = int(((fr["flags"] & capi.F_CRC_OK) != 0).sum()) if want_pdus else None
 
     result = None
     if rank == 0:
         bpf = algorithmic_bytes_per_frame(SLOT_LEN, n_sym, n_bpsc)
+        # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate passes, FETCH_SIZE x2 per MI355X_MICROARCH.md and tools/calib_fetch.hip): collected by
+        # tools/pmc.sh, committed as profiles/*_traffic.json -- a bench run cannot count PMCs itself
+        traffic = None
+        try:
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+            with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
+                tj = json.load(f)
+            traffic = tj["hbm_bytes_per_frame"] * n_frames / 1e9
+        except Exception:
+            traffic = None
         achieved = bpf * n_frames / (kernel_ms_avg * 1e-3)
         result = {
             "metric": "OFDM demod throughput (complex samples/s), 802.11a RX chain sync->LLR",
@@ -167,19 +206,21 @@ def main():
                 "frames_per_gpu": n_frames, "slot_len": SLOT_LEN, "encoding": "QPSK_1_2",
                 "outputs": "48 u8 decisions + 96 f32 LLRs per data symbol, 32 B frame record"
                            + ("; decode_mac + PSDU" if do_decode else ""),
-                "parallelism": "frames sharded %d-way, all-gather of PDUs" % world if world > 1 else "1 GPU",
+                "parallelism": "frames sharded %d-way, no collective on the hot path" % world if world > 1 else "1 GPU",
             },
             "gsamples_per_s": value / 1e9,
             "msymbols_per_s": float(n_frames) * (n_sym + 3) * world * args.steps / elapsed / 1e6,
             "frames_complete": n_complete,
             "frames_crc_ok": n_crc,
+            "pdu_leg": pdu_leg,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "GB per launch (PMC, profiles/*_traffic.json)",
                 "kernel": "wr::demod_batch_kernel",
                 "kernel_ms": kernel_ms_avg,
                 "algorithmic_bytes_per_frame": bpf,
@@ -207,6 +248,12 @@ def main():
         g_fr = fr[:n_cpu].copy()
         g_fr["flags"] &= ~np.uint32(capi.F_DECODED | capi.F_CRC_OK)
         mism = int((g_idx != o["idx"]).sum()) + int((g_llr != o["llr"]).sum()) + int((g_fr != o["frames"]).sum())
+        if want_pdus:       # decoded PSDUs of the same frames against the oracle's decode_mac
+            n_dec = min(n_cpu, 8192)
+            of = o["frames"][:n_dec].copy()
+            opsdu = orc.decode_batch(of, o["idx"][:n_dec], prm, psdu_stride=psdu_stride, n_threads=cores)
+            g_psdu = psdu_t[:n_dec].cpu().numpy()
+            mism += int((g_psdu[:, :PSDU_LEN] != opsdu[:, :PSDU_LEN]).sum()) + int((of["flags"] != fr[:n_dec]["flags"]).sum())
         result["cpu_baseline"] = {
             "value": n_cpu * SLOT_LEN / dt,
             "unit": "samples/s",
