@@ -228,7 +228,7 @@ def main():
         }
 
     # ---- cpu_baseline leg: the oracle on this host's cores, bounded sample of the same batch ----
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # contract: rank 0 at N=1 only
         from oracle import oracle as orc
         cores = os.cpu_count() or 1
         prm = orc.make_params(bandwidth=BANDWIDTH, frequency=FREQUENCY, max_sym=n_sym, llr_bits=n_bpsc)
