@@ -254,8 +254,13 @@ def main():
             opsdu = orc.decode_batch(of, o["idx"][:n_dec], prm, psdu_stride=psdu_stride, n_threads=cores)
             g_psdu = psdu_t[:n_dec].cpu().numpy()
             mism += int((g_psdu[:, :PSDU_LEN] != opsdu[:, :PSDU_LEN]).sum()) + int((of["flags"] != fr[:n_dec]["flags"]).sum())
+        n1 = max(64, min(n_cpu, int(rate / cores * 1.5)))          # ~1.5 s on one thread
+        t = time.perf_counter()
+        orc.demod_batch(x[:n1 * SLOT_LEN], SLOT_LEN, prm, n_threads=1)
+        dt1 = time.perf_counter() - t
         result["cpu_baseline"] = {
             "value": n_cpu * SLOT_LEN / dt,
+            "value_1thread": n1 * SLOT_LEN / dt1,
             "unit": "samples/s",
             "cores": cores,
             "kind": "port",

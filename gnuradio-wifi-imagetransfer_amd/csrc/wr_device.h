@@ -40,6 +40,23 @@ __device__ __forceinline__ void sp_sincos(float x, float& s, float& c)
     c = ((k + 1) & 2) ? -c0 : c0;
 }
 
+// sp_sincos for callers whose angles are usually small: when every lane has |x * 2/pi| < 0.5 the reduction
+// of sp_sincos yields k = 0 and r = x exactly, so the polynomials alone give bit-identical results.
+__device__ __forceinline__ void sp_sincos_small(float x, float& s, float& c)
+{
+    if (__all(__builtin_fabsf(x * WR_TWO_OVER_PI) < 0.5f)) {
+        float z  = x * x;
+        float ps = fma_(z, WR_S3, WR_S2);
+        ps = fma_(ps, z, WR_S1);
+        s = fma_(ps * z, x, x);
+        float pc = fma_(z, WR_C3, WR_C2);
+        pc = fma_(pc, z, WR_C1);
+        c = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
+    } else {
+        sp_sincos(x, s, c);
+    }
+}
+
 // sine/cosine of a double angle: reduction by pi/2 in double, polynomials in float (spec section 4.1)
 __device__ __forceinline__ void sp_sincos_d(double x, float& s, float& c)
 {

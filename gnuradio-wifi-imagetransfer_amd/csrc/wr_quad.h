@@ -329,6 +329,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     const long  m_hi_l = seed.n_samp - t16;
     const int   m_hi = has ? (int)(m_hi_l > 0x7fffff00l ? 0x7fffff00l : m_hi_l) : 0;
     const int   L = (int)seed.L;
+    const bool  lo_zero = __all(m_lo == 0 && L <= m_hi);      // wave-uniform: no row starts before its stream does
     const int   out = (int)seed.out;
     const int   trig = (int)seed.t;
     const float cfo_c = seed.cfo_c, cfo_f = seed.cfo_f;
@@ -410,7 +411,13 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 nx[j] = load_y(xb, offn + r + 16 * j, m_lo, m_hi);
 #else
                 (void)offn;
-                cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
+                if (lo_zero) {          // act => off0 + 63 < L <= m_hi: every sample of the symbol is in range
+                    float2 t = make_float2(0.0f, 0.0f);
+                    if (act) t = xb[off0 + r + 16 * j];
+                    cur[j] = { t.x, t.y };
+                } else {
+                    cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
+                }
 #endif
             }
         }
@@ -461,8 +468,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         {
             double t4 = two_pi * s * 80 * (eps0 + d_er);
             c32 step, q;
-            sp_sincos((float)(t4 * 16.0 / 64), step.im, step.re);
-            sp_sincos((float)(t4 * (double)(r - 32) / 64), q.im, q.re);
+            sp_sincos_small((float)(t4 * 16.0 / 64), step.im, step.re);
+            sp_sincos_small((float)(t4 * (double)(r - 32) / 64), q.im, q.re);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 X[j] = sp_cmul(X[j], q);
@@ -505,8 +512,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         {
             float n2 = fma_(S.im, S.im, S.re * S.re);
             float nn = __builtin_sqrtf(n2);
-            float cs = (nn > 0.0f) ? S.re / nn : 1.0f;
-            float sn = (nn > 0.0f) ? -S.im / nn : 0.0f;
+            float inv = 1.0f / nn;
+            float cs = (nn > 0.0f) ? S.re * inv : 1.0f;
+            float sn = (nn > 0.0f) ? -(S.im * inv) : 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; j++) X[j] = sp_rot(X[j], sn, cs);
         }

@@ -741,15 +741,16 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             er = (double)erf * (bw / (2 * M_PI * fc * 80));
         }
         memcpy(prev, cur, sizeof prev);
-        /* (4) derotate by -beta.  Spec (section 4.9): exp(-j beta) = conj(S)/|S| with a correctly rounded sqrt and two
-         * divisions, no atan2/sincos round trip; S = 0 rotates by 0 like arg(0) = 0. */
+        /* (4) derotate by -beta.  Spec (section 4.10): exp(-j beta) = conj(S) * (1/|S|) with a correctly rounded sqrt and
+         * one division, no atan2/sincos round trip; S = 0 rotates by 0 like arg(0) = 0. */
         {
             float sn, cs;
             if (spec) {
                 float n2 = fmaf(S.im, S.im, S.re * S.re);
                 float nn = sqrtf(n2);
-                cs = (nn > 0.0f) ? S.re / nn : 1.0f;
-                sn = (nn > 0.0f) ? -S.im / nn : 0.0f;
+                float inv = 1.0f / nn;
+                cs = (nn > 0.0f) ? S.re * inv : 1.0f;
+                sn = (nn > 0.0f) ? -(S.im * inv) : 0.0f;
             } else {
                 sincosf(-beta, &sn, &cs);
             }
