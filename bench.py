@@ -105,7 +105,7 @@ def main():
     psdu_stride = 320
     psdu_t = torch.zeros((n_frames, psdu_stride), dtype=torch.uint8, device="cuda") if want_pdus else None
     out = capi.Out(frames_t.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), None,
-                   psdu_t.data_ptr() if want_pdus else None, psdu_stride if want_pdus else 0, 1)
+                   psdu_t.data_ptr() if want_pdus else None, psdu_stride if want_pdus else 0, 1, None)
     def step():
         """one pass of the hot path; returns the demod kernel's HIP-event time in ms"""
         ms = capi.C.c_float(0)

@@ -42,6 +42,7 @@ struct wifirx_handle {
     void*  stage_llr = nullptr;     size_t stage_llr_bytes = 0;
     void*  stage_car = nullptr;     size_t stage_car_bytes = 0;
     void*  stage_psdu = nullptr;    size_t stage_psdu_bytes = 0;
+    void*  stage_csi = nullptr;     size_t stage_csi_bytes = 0;
 
     // decode workspace
     void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;
@@ -97,6 +98,8 @@ wr::DemodParams params_of(const wifirx_handle* h)
     p.min_plateau = h->cfg.min_plateau;
     p.max_sym = h->cfg.max_sym;
     p.llr_bits = h->cfg.llr_bits;
+    p.chan_est = h->cfg.chan_est;
+    p.pad_ = 0;
     return p;
 }
 
@@ -116,7 +119,8 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
     if (cfg->max_sym == 0 || cfg->max_sym > WIFIRX_MAX_SYM) return fail(nullptr, WIFIRX_EINVAL, "max_sym out of range");
     if (!(cfg->llr_bits == 0 || cfg->llr_bits == 1 || cfg->llr_bits == 2 || cfg->llr_bits == 4 || cfg->llr_bits == 6))
         return fail(nullptr, WIFIRX_EINVAL, "llr_bits must be 0,1,2,4,6");
-    if (cfg->chan_est != WIFIRX_EQ_LS) return fail(nullptr, WIFIRX_EINVAL, "only the LS equalizer is implemented");
+    if (cfg->chan_est != WIFIRX_EQ_LS && cfg->chan_est != WIFIRX_EQ_LMS)
+        return fail(nullptr, WIFIRX_EINVAL, "only the LS and LMS equalizers are implemented");
     if (!(cfg->bandwidth > 0) || !(cfg->frequency > 0)) return fail(nullptr, WIFIRX_EINVAL, "bandwidth/frequency must be > 0");
     if (cfg->min_plateau < 0 || cfg->min_plateau > 32) return fail(nullptr, WIFIRX_EINVAL, "min_plateau out of range");
     int ndev = 0;
@@ -144,7 +148,7 @@ int wifirx_destroy(wifirx_handle* h)
     if (!h) return WIFIRX_EINVAL;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu,
+    void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi,
                      h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx, h->s_llr,
                      h->s_car, h->s_psdu };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -169,7 +173,8 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
         h->cfg.sensitivity = (float)value;
         return WIFIRX_OK;
     case WIFIRX_P_CHAN_EST:
-        if ((int)value != WIFIRX_EQ_LS) return fail(h, WIFIRX_EINVAL, "only the LS equalizer is implemented");
+        if ((int)value != WIFIRX_EQ_LS && (int)value != WIFIRX_EQ_LMS)
+            return fail(h, WIFIRX_EINVAL, "only the LS and LMS equalizers are implemented");
         h->cfg.chan_est = (int)value;
         return WIFIRX_OK;
     default:
@@ -263,6 +268,7 @@ int wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device, uint
     uint8_t* d_idx = out->idx;
     float*   d_llr = out->llr;
     float2*  d_car = reinterpret_cast<float2*>(out->carrier);
+    float2*  d_csi = reinterpret_cast<float2*>(out->csi);
     if (!out->on_device) {
         if ((rc = ensure(h, &h->stage_frames, &h->stage_frames_bytes, n_slots * sizeof(wifirx_frame)))) return rc;
         d_fr = reinterpret_cast<wifirx_frame*>(h->stage_frames);
@@ -281,14 +287,20 @@ int wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device, uint
             d_car = reinterpret_cast<float2*>(h->stage_car);
             HIP_TRY(h, hipMemsetAsync(d_car, 0, idx_n * sizeof(float2), h->stream));
         }
+        if (out->csi) {
+            if ((rc = ensure(h, &h->stage_csi, &h->stage_csi_bytes, (size_t)n_slots * 52 * sizeof(float2)))) return rc;
+            d_csi = reinterpret_cast<float2*>(h->stage_csi);
+            HIP_TRY(h, hipMemsetAsync(d_csi, 0, (size_t)n_slots * 52 * sizeof(float2), h->stream));
+        }
     }
-    HIP_TRY(h, wr_launch_demod_batch(h->stream, d_iq, slot_len, n_slots, &prm, d_fr, d_idx, d_llr, d_car));
+    HIP_TRY(h, wr_launch_demod_batch(h->stream, d_iq, slot_len, n_slots, &prm, d_fr, d_idx, d_llr, d_car, d_csi));
     h->stats.samples_in += n_iq;
     if (!out->on_device) {
         HIP_TRY(h, hipMemcpyAsync(out->frames, d_fr, n_slots * sizeof(wifirx_frame), hipMemcpyDeviceToHost, h->stream));
         if (out->idx) HIP_TRY(h, hipMemcpyAsync(out->idx, d_idx, idx_n, hipMemcpyDeviceToHost, h->stream));
         if (out->llr) HIP_TRY(h, hipMemcpyAsync(out->llr, d_llr, idx_n * h->cfg.llr_bits * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         if (out->carrier) HIP_TRY(h, hipMemcpyAsync(out->carrier, d_car, idx_n * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+        if (out->csi) HIP_TRY(h, hipMemcpyAsync(out->csi, d_csi, (size_t)n_slots * 52 * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         for (uint32_t i = 0; i < n_slots; i++) {
             uint32_t f = out->frames[i].flags;
@@ -315,7 +327,8 @@ int wifirx_time_demod(wifirx_handle* h, const float* iq_dev, uint32_t slot_len, 
     for (int i = 0; i < iters; i++) {
         HIP_TRY(h, hipEventRecord(e0, h->stream));
         HIP_TRY(h, wr_launch_demod_batch(h->stream, reinterpret_cast<const float2*>(iq_dev), slot_len, n_slots, &prm,
-                                         out->frames, out->idx, out->llr, reinterpret_cast<float2*>(out->carrier)));
+                                         out->frames, out->idx, out->llr, reinterpret_cast<float2*>(out->carrier),
+                                         reinterpret_cast<float2*>(out->csi)));
         HIP_TRY(h, hipEventRecord(e1, h->stream));
         HIP_TRY(h, hipEventSynchronize(e1));
         float ms = 0;

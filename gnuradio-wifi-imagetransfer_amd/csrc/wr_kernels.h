@@ -23,6 +23,8 @@ struct DemodParams {
     int32_t  min_plateau;
     uint32_t max_sym;
     uint32_t llr_bits;
+    int32_t  chan_est;      // WIFIRX_EQ_LS / WIFIRX_EQ_LMS
+    int32_t  pad_;
 };
 
 // one detected frame of a continuous stream (stream mode)
@@ -38,7 +40,7 @@ struct StreamTrig {
 extern "C" {
 hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot_len, uint32_t n_slots,
                                  const wr::DemodParams* prm, wifirx_frame* frames, uint8_t* idx,
-                                 float* llr, float2* carrier);
+                                 float* llr, float2* carrier, float2* csi);
 hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_templates, uint32_t frame_len,
                            float2* slots, uint32_t slot_len, uint32_t n_slots, uint32_t lead, float gain,
                            float cfo_max, uint64_t seed, float* cfo_out);
@@ -51,5 +53,5 @@ hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_sa
                                    int64_t n_tiles, float thr, uint64_t* masks, float2* A);
 hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
                                   uint32_t n_trig, const wr::DemodParams* prm, const float2* A,
-                                  wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier);
+                                  wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier, float2* csi);
 }

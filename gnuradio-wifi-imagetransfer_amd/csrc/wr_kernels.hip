@@ -129,10 +129,11 @@ __device__ __forceinline__ uint32_t sync_after_trigger(const float2* x, long n_s
     return ok ? (WIFIRX_F_DETECTED | WIFIRX_F_SYNC) : WIFIRX_F_DETECTED;
 }
 
-__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, WR_DEMOD_WAVES_PER_SIMD)
+template <bool LMS>
+__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, LMS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
                         DemodParams prm, wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
-                        float* __restrict__ llr, float2* __restrict__ carrier)
+                        float* __restrict__ llr, float2* __restrict__ carrier, float2* __restrict__ csi)
 {
     __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS];
     const int lane = threadIdx.x & 63;
@@ -165,7 +166,7 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
     if ((lane & 15) == 0 && seed.out >= 0) { frames[seed.out].flags = seed.flags; frames[seed.out].frame_start = seed.fs; frames[seed.out].cfo_fine = seed.cfo_f; frames[seed.out].trigger = (int)seed.t; }
     return;
 #endif
-    frames_quad(seed, prm, lds[wave], lane, frames, idx, llr, carrier);
+    frames_quad<LMS>(seed, prm, lds[wave], lane, frames, idx, llr, carrier, csi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,11 +195,12 @@ void stream_detect_kernel(const float2* __restrict__ x, long n_samp, long tile0,
 }
 
 // one wave per four selected triggers of the stream
-__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, WR_DEMOD_WAVES_PER_SIMD)
+template <bool LMS>
+__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, LMS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
 void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const StreamTrig* __restrict__ trig,
                          uint32_t n_trig, DemodParams prm, const float2* __restrict__ A,
                          wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
-                         float* __restrict__ llr, float2* __restrict__ carrier)
+                         float* __restrict__ llr, float2* __restrict__ carrier, float2* __restrict__ csi)
 {
     __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS];
     const int lane = threadIdx.x & 63;
@@ -223,18 +225,21 @@ void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const Stream
             seed.fs = fs; seed.flags = flags; seed.out = k;
         }
     }
-    frames_quad(seed, prm, lds[wave], lane, frames, idx, llr, carrier);
+    frames_quad<LMS>(seed, prm, lds[wave], lane, frames, idx, llr, carrier, csi);
 }
 
 }  // namespace wr
 
 extern "C" hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot_len,
                                             uint32_t n_slots, const wr::DemodParams* prm,
-                                            wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier)
+                                            wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier, float2* csi)
 {
     if (n_slots == 0) return hipSuccess;
     dim3 grid((n_slots + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
-    hipLaunchKernelGGL(wr::demod_batch_kernel, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier);
+    if (prm->chan_est == WIFIRX_EQ_LMS)
+        hipLaunchKernelGGL(wr::demod_batch_kernel<true>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi);
+    else
+        hipLaunchKernelGGL(wr::demod_batch_kernel<false>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi);
     return hipGetLastError();
 }
 
@@ -250,10 +255,13 @@ extern "C" hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, i
 
 extern "C" hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
                                              uint32_t n_trig, const wr::DemodParams* prm, const float2* A,
-                                             wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier)
+                                             wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier, float2* csi)
 {
     if (n_trig == 0) return hipSuccess;
     dim3 grid((n_trig + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
-    hipLaunchKernelGGL(wr::demod_stream_kernel, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier);
+    if (prm->chan_est == WIFIRX_EQ_LMS)
+        hipLaunchKernelGGL(wr::demod_stream_kernel<true>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi);
+    else
+        hipLaunchKernelGGL(wr::demod_stream_kernel<false>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi);
     return hipGetLastError();
 }

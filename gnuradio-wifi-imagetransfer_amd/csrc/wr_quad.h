@@ -313,9 +313,40 @@ __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrie
 
 // ---------------------------------------------------------------------------------------------
 // a3 copy + a4 + a5 + a6 + a7 for the four frames of a wave.
+// the constellation point of an index (levels formed in float32 as the upstream constellations do)
+__device__ __forceinline__ c32 point_of(unsigned idx, int n_bpsc)
+{
+    c32 p;
+    if (n_bpsc == 1) { p.re = (idx & 1) ? 1.0f : -1.0f; p.im = 0.0f; return p; }
+    if (n_bpsc == 2) {
+        p.re = (idx & 1) ? WR_LEVEL_QPSK : -WR_LEVEL_QPSK;
+        p.im = (idx & 2) ? WR_LEVEL_QPSK : -WR_LEVEL_QPSK;
+        return p;
+    }
+    if (n_bpsc == 4) {
+        const float l = WR_T16_2 * 0.5f;
+        float ar = (idx & 2) ? l : 3.0f * l, ai = (idx & 8) ? l : 3.0f * l;
+        p.re = (idx & 1) ? ar : -ar;
+        p.im = (idx & 4) ? ai : -ai;
+        return p;
+    }
+    const float l = WR_T64_2 * 0.5f;
+    unsigned r = (idx >> 1) & 3, q = (idx >> 4) & 3;
+    unsigned kr = ((r & 1) << 1) | (r >> 1), kq = ((q & 1) << 1) | (q >> 1);     // 0,1,2,3 -> 7a,5a,1a,3a
+    float ar = (kr == 0 ? 7.0f : kr == 1 ? 5.0f : kr == 2 ? 1.0f : 3.0f) * l;
+    float ai = (kq == 0 ? 7.0f : kq == 1 ? 5.0f : kq == 2 ? 1.0f : 3.0f) * l;
+    p.re = (idx & 1) ? ar : -ar;
+    p.im = (idx & 8) ? ai : -ai;
+    return p;
+}
+
+// LMS = false: LS equaliser (channel estimate from the LTS, held for the frame; multiplier form).
+// LMS = true:  decision-directed LMS (ieee802_11.LMS): Y = X/H, then H = H/2 + (X/point)/2 on every data bin.
+template <bool LMS>
 __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodParams& prm, float* qlds, int lane,
                                             wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx_all,
-                                            float* __restrict__ llr_all, float2* __restrict__ car_all)
+                                            float* __restrict__ llr_all, float2* __restrict__ car_all,
+                                            float2* __restrict__ csi_all)
 {
     const int row = lane >> 4, r = lane & 15;
     // ---- row-uniform frame state, one copy per lane ----
@@ -539,9 +570,15 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 nv[j] = usedj ? fma_(d.im, d.im, d.re * d.re) : 0.0f;
                 sv[j] = usedj ? fma_(u.im, u.im, u.re * u.re) : 0.0f;
                 float g = 0.5f * WR_LTS_FREQ[i];
-                // G = conj(H)/|H|^2 replaces H in LDS: the one-tap equaliser as a multiplier
-                const float hr = u.re * g, hi = u.im * g, dd = fma_(hi, hi, hr * hr);
-                Hl[64 * j] = usedj ? make_float2(hr / dd, -hi / dd) : make_float2(0.0f, 0.0f);
+                const float hr = u.re * g, hi = u.im * g;
+                if (csi_all && usedj && act) csi_all[(size_t)out * 52 + (i - 6 - (i > 32))] = make_float2(hr, hi);
+                if (LMS) {
+                    Hl[64 * j] = usedj ? make_float2(hr, hi) : make_float2(1.0f, 0.0f);
+                } else {
+                    // G = conj(H)/|H|^2 replaces H in LDS: the one-tap equaliser as a multiplier
+                    const float dd = fma_(hi, hi, hr * hr);
+                    Hl[64 * j] = usedj ? make_float2(hr / dd, -hi / dd) : make_float2(0.0f, 0.0f);
+                }
                 // the spec's xor tree over the 64 bins: steps 1,2,4,8 inside the row ...
                 nv[j] = row_xor_sum16(nv[j]);
                 sv[j] = row_xor_sum16(sv[j]);
@@ -560,7 +597,19 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 Y[j] = { 0.0f, 0.0f };
                 if (carrier[j] >= 0) {
                     const float2 g0 = Hl[64 * j];
-                    Y[j] = sp_cmul(X[j], c32{ g0.x, g0.y });
+                    if (LMS) {
+                        const float d = fma_(g0.y, g0.y, g0.x * g0.x);
+                        Y[j].re = fma_(X[j].im, g0.y, X[j].re * g0.x) / d;
+                        Y[j].im = fma_(X[j].im, g0.x, -(X[j].re * g0.y)) / d;
+                        const int nbl = (s == 2) ? 1 : n_bpsc;
+                        const c32 pt = point_of(decide(Y[j], nbl), nbl);
+                        const float dp = fma_(pt.im, pt.im, pt.re * pt.re);
+                        const float tr = fma_(X[j].im, pt.im, X[j].re * pt.re) / dp;
+                        const float ti = fma_(X[j].im, pt.re, -(X[j].re * pt.im)) / dp;
+                        if (act) Hl[64 * j] = make_float2(0.5f * g0.x + 0.5f * tr, 0.5f * g0.y + 0.5f * ti);
+                    } else {
+                        Y[j] = sp_cmul(X[j], c32{ g0.x, g0.y });
+                    }
                 }
             }
             if (s == 2) {

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwifirx.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 EQ_LS, EQ_LMS, EQ_COMB, EQ_STA = 0, 1, 2, 3
 P_BANDWIDTH, P_FREQUENCY, P_SENSITIVITY, P_CHAN_EST = 1, 2, 3, 4
 F_DETECTED, F_SYNC, F_SIGNAL, F_COMPLETE, F_LLR, F_DECODED, F_CRC_OK = 1, 2, 4, 8, 16, 32, 64
@@ -50,7 +50,7 @@ class Config(C.Structure):
 
 class Out(C.Structure):
     _fields_ = [("frames", C.c_void_p), ("idx", C.c_void_p), ("llr", C.c_void_p), ("carrier", C.c_void_p),
-                ("psdu", C.c_void_p), ("psdu_stride", C.c_uint32), ("on_device", C.c_uint32)]
+                ("psdu", C.c_void_p), ("psdu_stride", C.c_uint32), ("on_device", C.c_uint32), ("csi", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -178,7 +178,7 @@ class WifiRx:
         return DevBuf(self, nbytes)
 
     # -- batch mode, host buffers (PCIe-bound convenience path) --
-    def demod_batch(self, iq: np.ndarray, slot_len: int, decode=False, psdu_stride=2048) -> dict:
+    def demod_batch(self, iq: np.ndarray, slot_len: int, decode=False, psdu_stride=2048, want_csi=False) -> dict:
         iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
         n_slots = iq.size // slot_len
         assert n_slots * slot_len == iq.size
@@ -189,9 +189,10 @@ class WifiRx:
         car = np.zeros((n_slots, ms, 48), dtype=np.complex64) if self.cfg.want_carrier else None
         psdu = np.zeros((n_slots, psdu_stride), dtype=np.uint8) if decode else None
         if not decode:
-            out = Out(_np_ptr(frames), _np_ptr(idx), _np_ptr(llr), _np_ptr(car), None, 0, 0)
+            csi = np.zeros((n_slots, 52), dtype=np.complex64) if want_csi else None
+            out = Out(_np_ptr(frames), _np_ptr(idx), _np_ptr(llr), _np_ptr(car), None, 0, 0, _np_ptr(csi))
             self._check(_lib.wifirx_demod_batch(self._h, _np_ptr(iq), 0, slot_len, n_slots, C.byref(out)))
-            return dict(frames=frames, idx=idx, llr=llr, carrier=car, psdu=None)
+            return dict(frames=frames, idx=idx, llr=llr, carrier=car, psdu=None, csi=csi)
         # decode needs the decisions on the device: run on device buffers, then download
         d_iq = self.alloc(iq.nbytes).upload(iq)
         dev = self.alloc_out(n_slots, psdu_stride=psdu_stride)
@@ -225,7 +226,7 @@ class WifiRx:
 
     def _out_struct(self, dev) -> Out:
         g = lambda k: dev[k].ptr if dev.get(k) is not None else None
-        return Out(g("frames"), g("idx"), g("llr"), g("carrier"), g("psdu"), dev.get("psdu_stride", 0), 1)
+        return Out(g("frames"), g("idx"), g("llr"), g("carrier"), g("psdu"), dev.get("psdu_stride", 0), 1, None)
 
     def demod_batch_dev(self, iq_ptr, slot_len, n_slots, dev):
         out = self._out_struct(dev)

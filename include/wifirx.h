@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WIFIRX_ABI_VERSION 1
+#define WIFIRX_ABI_VERSION 2
 
 /* error codes */
 #define WIFIRX_OK        0
@@ -96,7 +96,7 @@ typedef struct wifirx_config {
     double   frequency;    /* carrier in Hz:    wifi_phy_hier `frequency` (grc:501-510) */
     float    sensitivity;  /* sync_short threshold: wifi_phy_hier `sensitivity` (grc:681-690), 0.56 */
     int32_t  min_plateau;  /* sync_short min_plateau, 2 (gnu_radio/IRS_AP.py:268) */
-    int32_t  chan_est;     /* WIFIRX_EQ_*: wifi_phy_hier `chan_est` (grc:299-308); LS implemented */
+    int32_t  chan_est;     /* WIFIRX_EQ_*: wifi_phy_hier `chan_est` (grc:299-308); LS and LMS implemented */
     uint32_t max_sym;      /* output capacity per frame in data symbols (<= WIFIRX_MAX_SYM) */
     uint32_t llr_bits;     /* LLR capacity per sub-carrier (0 = no LLR output, else 1,2,4,6) */
     uint32_t want_carrier; /* 1: also write the 48 equalised points per symbol (`carrier` port) */
@@ -123,6 +123,10 @@ typedef struct wifirx_handle wifirx_handle;
  *   carrier [n_slots][max_sym][48][2]         equalised points (re,im): the `symbols` message port
  *   psdu    [n_slots][psdu_stride]            decode_mac output: MAC frame incl. FCS position
  *                                              (bytes 0..psdu_len-1), valid when WIFIRX_F_CRC_OK
+ *   csi     [n_slots][52][2]                  channel state (re,im) on the 52 occupied sub-carriers in ascending
+ *                                              order: the LS estimate from the two long training symbols (what
+ *                                              the reference's disabled extract_csi block taps,
+ *                                              gnu_radio/IRS_AP.grc:640-654); written once SYNC is set
  */
 typedef struct wifirx_out {
     wifirx_frame* frames;
@@ -132,6 +136,7 @@ typedef struct wifirx_out {
     uint8_t*      psdu;
     uint32_t      psdu_stride;  /* bytes per slot in `psdu` (>= largest psdu_len expected) */
     uint32_t      on_device;
+    float*        csi;          /* ABI 2 */
 } wifirx_out;
 
 typedef struct wifirx_stats {

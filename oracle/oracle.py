@@ -30,7 +30,7 @@ F_DETECTED, F_SYNC, F_SIGNAL, F_COMPLETE, F_LLR, F_DECODED, F_CRC_OK = 1, 2, 4, 
 class Params(C.Structure):
     _fields_ = [("bandwidth", C.c_double), ("frequency", C.c_double), ("threshold", C.c_float),
                 ("min_plateau", C.c_int32), ("math_mode", C.c_int32), ("max_sym", C.c_int32),
-                ("llr_bits", C.c_int32), ("reserved", C.c_int32)]
+                ("llr_bits", C.c_int32), ("chan_est", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -60,11 +60,11 @@ def _p(a):
 
 
 def make_params(bandwidth=20e6, frequency=5.89e9, threshold=0.56, min_plateau=2,
-                math_mode=MATH_SPEC, max_sym=64, llr_bits=0) -> Params:
-    return Params(bandwidth, frequency, threshold, min_plateau, math_mode, max_sym, llr_bits, 0)
+                math_mode=MATH_SPEC, max_sym=64, llr_bits=0, chan_est=0) -> Params:
+    return Params(bandwidth, frequency, threshold, min_plateau, math_mode, max_sym, llr_bits, chan_est)
 
 
-def demod_batch(iq: np.ndarray, slot_len: int, prm: Params, want_eq=False, n_threads=1):
+def demod_batch(iq: np.ndarray, slot_len: int, prm: Params, want_eq=False, n_threads=1, want_csi=False):
     """iq: complex64 [n_slots*slot_len]. Returns dict(frames, idx, llr, eq)."""
     iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
     n_slots = iq.size // slot_len
@@ -72,10 +72,11 @@ def demod_batch(iq: np.ndarray, slot_len: int, prm: Params, want_eq=False, n_thr
     idx = np.zeros((n_slots, prm.max_sym, 48), dtype=np.uint8)
     llr = np.zeros((n_slots, prm.max_sym * 48 * prm.llr_bits), dtype=np.float32) if prm.llr_bits else None
     eq = np.zeros((n_slots, prm.max_sym, 48), dtype=np.complex64) if want_eq else None
+    csi = np.zeros((n_slots, 52), dtype=np.complex64) if want_csi else None
     rc = lib().orc_demod_batch(_p(iq), C.c_uint32(slot_len), C.c_uint32(n_slots), C.byref(prm),
-                               _p(frames), _p(idx), _p(llr), _p(eq), C.c_int(n_threads))
+                               _p(frames), _p(idx), _p(llr), _p(eq), _p(csi), C.c_int(n_threads))
     assert rc == 0
-    return dict(frames=frames, idx=idx, llr=llr, eq=eq)
+    return dict(frames=frames, idx=idx, llr=llr, eq=eq, csi=csi)
 
 
 def decode_batch(frames: np.ndarray, idx: np.ndarray, prm: Params, psdu_stride=2048, n_threads=1):

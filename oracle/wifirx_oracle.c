@@ -50,7 +50,7 @@ typedef struct orc_params {
     int32_t math_mode;
     int32_t max_sym;      /* output capacity per frame (data symbols) */
     int32_t llr_bits;     /* 0: no llr */
-    int32_t reserved;
+    int32_t chan_est;     /* WIFIRX_EQ_LS or WIFIRX_EQ_LMS */
 } orc_params;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -499,6 +499,35 @@ static inline uint8_t decide(c32 y, int n_bpsc)
     }
 }
 
+/* the constellation point of an index (levels formed in float32 as the upstream constellations do) */
+static inline c32 point_of(unsigned idx, int n_bpsc)
+{
+    c32 p;
+    if (n_bpsc == 1) { p.re = (idx & 1) ? 1.0f : -1.0f; p.im = 0.0f; return p; }
+    if (n_bpsc == 2) {
+        p.re = (idx & 1) ? WR_LEVEL_QPSK : -WR_LEVEL_QPSK;
+        p.im = (idx & 2) ? WR_LEVEL_QPSK : -WR_LEVEL_QPSK;
+        return p;
+    }
+    if (n_bpsc == 4) {
+        const float l = WR_T16_2 * 0.5f;
+        float ar = (idx & 2) ? l : 3.0f * l, ai = (idx & 8) ? l : 3.0f * l;
+        p.re = (idx & 1) ? ar : -ar;
+        p.im = (idx & 4) ? ai : -ai;
+        return p;
+    }
+    {
+        const float l = WR_T64_2 * 0.5f;
+        /* per axis: bit1 = |u| < 4a, bit2 = 2a < |u| < 6a  ->  |u| = 7a,5a,1a,3a for (b1,b2) = 00,01,10,11 */
+        unsigned r = (idx >> 1) & 3, q = (idx >> 4) & 3;
+        float tab[4] = { 7.0f * l, 5.0f * l, 1.0f * l, 3.0f * l };
+        float ar = tab[((r & 1) << 1) | (r >> 1)], ai = tab[((q & 1) << 1) | (q >> 1)];
+        p.re = (idx & 1) ? ar : -ar;
+        p.im = (idx & 8) ? ai : -ai;
+        return p;
+    }
+}
+
 /* a7: max-log piecewise-linear LLRs, positive <=> bit 1 (unscaled form) */
 static inline void llr_of(c32 y, int n_bpsc, float* out)
 {
@@ -543,7 +572,7 @@ static inline c32 x_at(const c32* x, long n_samp, long n)
 }
 
 void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc_params* prm,
-               wifirx_frame* fr, uint8_t* idx, float* llr, c32* eq)
+               wifirx_frame* fr, uint8_t* idx, float* llr, c32* eq, c32* csi)
 {
     const int spec = prm->math_mode == ORC_MATH_SPEC;
     fr->flags = WIFIRX_F_DETECTED;
@@ -800,6 +829,10 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 snr = (float)(10 * log10(signal / noise / 2));
             }
             fr->snr_db = snr;
+            if (csi) {            /* channel state: the LS estimate on the 52 occupied bins, ascending */
+                int k = 0;
+                for (int i = 6; i <= 58; i++) if (i != 32) csi[k++] = H[i];
+            }
         } else {
             uint8_t bits48[48];
             c32     sym48[48];
@@ -808,8 +841,26 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             for (int i = 0; i < 64; i++) {
                 if (i == 11 || i == 25 || i == 32 || i == 39 || i == 53 || i < 6 || i > 58) continue;
                 c32 yq;
-                if (spec) {
+                if (spec && prm->chan_est == WIFIRX_EQ_LMS) {
+                    /* LMS (decision directed): Y = X/H, then H = H/2 + (X/point)/2 */
+                    float d = fmaf(H[i].im, H[i].im, H[i].re * H[i].re);
+                    yq.re = fmaf(X[i].im, H[i].im, X[i].re * H[i].re) / d;
+                    yq.im = fmaf(X[i].im, H[i].re, -(X[i].re * H[i].im)) / d;
+                    c32 pt = point_of(decide(yq, nb), nb);
+                    float dp = fmaf(pt.im, pt.im, pt.re * pt.re);
+                    float tr = fmaf(X[i].im, pt.im, X[i].re * pt.re) / dp;
+                    float ti = fmaf(X[i].im, pt.re, -(X[i].re * pt.im)) / dp;
+                    H[i].re = 0.5f * H[i].re + 0.5f * tr;
+                    H[i].im = 0.5f * H[i].im + 0.5f * ti;
+                } else if (spec) {
                     yq = sp_cmul(X[i], G[i]);
+                } else if (prm->chan_est == WIFIRX_EQ_LMS) {
+                    float complex hv = H[i].re + I * H[i].im, xv = X[i].re + I * X[i].im;
+                    float complex v = xv / hv;
+                    yq.re = crealf(v); yq.im = cimagf(v);
+                    c32 pt = point_of(decide(yq, nb), nb);
+                    float complex nh = (0.5f + 0.0f * I) * hv + (0.5f + 0.0f * I) * (xv / (pt.re + I * pt.im));
+                    H[i].re = crealf(nh); H[i].im = cimagf(nh);
                 } else {
                     float complex v = (X[i].re + I * X[i].im) / (H[i].re + I * H[i].im);
                     yq.re = crealf(v); yq.im = cimagf(v);
@@ -911,7 +962,7 @@ int orc_decode_mac(const uint8_t* idx, int encoding, int psdu_len, uint8_t* psdu
 /* batch driver: every slot is an independent stream, first frame only                         */
 
 int orc_demod_batch(const c32* iq, uint32_t slot_len, uint32_t n_slots, const orc_params* prm,
-                    wifirx_frame* frames, uint8_t* idx, float* llr, c32* eq, int n_threads)
+                    wifirx_frame* frames, uint8_t* idx, float* llr, c32* eq, c32* csi, int n_threads)
 {
     long i;
     size_t idx_stride = (size_t)prm->max_sym * 48;
@@ -934,7 +985,7 @@ int orc_demod_batch(const c32* iq, uint32_t slot_len, uint32_t n_slots, const or
         orc_frame(x, slot_len, trig, cfo, L, prm, fr,
                   idx ? idx + i * idx_stride : NULL,
                   (llr && prm->llr_bits) ? llr + i * llr_stride : NULL,
-                  eq ? eq + i * idx_stride : NULL);
+                  eq ? eq + i * idx_stride : NULL, csi ? csi + (size_t)i * 52 : NULL);
     }
     return 0;
 }
@@ -975,7 +1026,7 @@ long orc_demod_stream(const c32* x, long n_samp, const orc_params* prm, wifirx_f
         orc_frame(x, n_samp, trig[k], cfo[k], L, prm, frames + k,
                   idx ? idx + k * idx_stride : NULL,
                   (llr && prm->llr_bits) ? llr + k * llr_stride : NULL,
-                  eq ? eq + k * idx_stride : NULL);
+                  eq ? eq + k * idx_stride : NULL, NULL);
     }
     free(trig);
     free(cfo);

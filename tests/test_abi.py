@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 18 and set(syms) == set(capi.EXPORTS)
     for s in syms:
         assert hasattr(capi.lib(), s), s
-    assert capi.lib().wifirx_abi_version() == capi.ABI_VERSION == 1
+    assert capi.lib().wifirx_abi_version() == capi.ABI_VERSION == 2
 
 
 def test_record_layouts():
@@ -36,7 +36,7 @@ def test_record_layouts():
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
-    assert sizes == [32, ctypes.sizeof(capi.Config), ctypes.sizeof(capi.Out), ctypes.sizeof(capi.Stats)] == [32, 56, 48, 48]
+    assert sizes == [32, ctypes.sizeof(capi.Config), ctypes.sizeof(capi.Out), ctypes.sizeof(capi.Stats)] == [32, 56, 56, 48]
     from oracle import oracle
     assert oracle.FRAME_DTYPE == capi.FRAME_DTYPE
 
@@ -58,8 +58,8 @@ def test_create_argument_checks():
     h = ctypes.c_void_p()
     bad = capi.Config(99, 0, 20e6, 5.89e9, 0.56, 2, 0, 64, 0, 0, 0, 0)
     assert capi.lib().wifirx_create(ctypes.byref(bad), ctypes.byref(h)) == -1
-    for kw in (dict(max_sym=0), dict(max_sym=512), dict(llr_bits=3), dict(chan_est=1), dict(bandwidth=0.0)):
-        vals = dict(abi_version=1, device=0, bandwidth=20e6, frequency=5.89e9, sensitivity=0.56, min_plateau=2,
+    for kw in (dict(max_sym=0), dict(max_sym=512), dict(llr_bits=3), dict(chan_est=2), dict(chan_est=3), dict(bandwidth=0.0)):
+        vals = dict(abi_version=2, device=0, bandwidth=20e6, frequency=5.89e9, sensitivity=0.56, min_plateau=2,
                     chan_est=0, max_sym=64, llr_bits=0, want_carrier=0, max_batch=0, max_slot_len=0)
         vals.update(kw)
         cfg = capi.Config(*[vals[f] for f, _ in capi.Config._fields_])

@@ -37,6 +37,8 @@ def test_empty_batch_and_argument_errors():
         rx.set_param(99, 1.0)
     with pytest.raises(capi.WifiRxError):
         rx.set_param(capi.P_CHAN_EST, capi.EQ_STA)
+    rx.set_param(capi.P_CHAN_EST, capi.EQ_LMS)
+    rx.set_param(capi.P_CHAN_EST, capi.EQ_LS)
     st = rx.stats()
     assert st["samples_in"] == 0
     rx.close()
