@@ -170,7 +170,9 @@ int  wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device,
 /* decode_mac over the hard decisions of a previous wifirx_demod_batch on the same buffers
  * (ieee802_11.decode_mac, gnu_radio/IRS_AP.py:272,291-292): de-interleave, de-puncture, Viterbi
  * K=7 (133,171), descramble, CRC-32.  Sets WIFIRX_F_DECODED / WIFIRX_F_CRC_OK in out->frames
- * and writes out->psdu. */
+ * and writes out->psdu.  Device buffers only (out->on_device = 1).  The call waits once for the
+ * stream (a pre-pass reads back the longest trellis of the batch to size the survivor scratch);
+ * the decode kernel itself is then queued asynchronously. */
 int  wifirx_decode_batch(wifirx_handle* h, uint32_t n_slots, const wifirx_out* out);
 
 /* Stream mode (what the GNU Radio block's work() calls): append `n` samples of the continuous
