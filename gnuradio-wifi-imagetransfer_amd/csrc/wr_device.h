@@ -79,6 +79,28 @@ __device__ __forceinline__ void sp_sincos_d(double x, float& s, float& c)
     c = ((k + 1) & 2) ? -c0 : c0;
 }
 
+// sine/cosine of a phase given in 2^-62 quarter turns modulo 2^64 (spec section 4.8): reduction = shift, quadrant = top bits
+__device__ __forceinline__ void sp_sincos_q(uint32_t p_hi, uint32_t p_lo, float& s, float& c)
+{
+    const uint32_t th = p_hi + 0x20000000u;
+    const int      k  = (int)(th >> 30);
+    const uint32_t uh = __builtin_amdgcn_alignbit(th, p_lo, 30);           // (th << 2) | (p_lo >> 30)
+    const int      gh = (int)(uh ^ 0x80000000u);
+    float r  = (float)gh * WR_PIO2_2M32;
+    float z  = r * r;
+    float ps = fma_(z, WR_S3, WR_S2);
+    ps = fma_(ps, z, WR_S1);
+    float sr = fma_(ps * z, r, r);
+    float pc = fma_(z, WR_C3, WR_C2);
+    pc = fma_(pc, z, WR_C1);
+    float cr = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
+    bool  odd = k & 1;
+    float s0 = odd ? cr : sr;
+    float c0 = odd ? sr : cr;
+    s = (k & 2) ? -s0 : s0;
+    c = ((k + 1) & 2) ? -c0 : c0;
+}
+
 __device__ __forceinline__ float sp_atan2(float y, float x)
 {
     float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);

@@ -373,9 +373,18 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     const double eps0 = tag * bw / (two_pi * fc);
     const double er_scale = bw / (two_pi * fc * 80);
     double d_er = 0.0;
-    const double theta_d = (double)cfo_f - (double)cfo_c;      // total derotation, rad/sample
+    // total derotation as an exact integer phase: Qp = 2^-62 quarter turns per sample; sample m has phase Qp*m
+    // mod 2^64.  `ph` holds the phase of this lane's first sample of the current symbol and advances by Qp*80
+    // (Qp*64 after the first long training symbol) -- two integer adds per symbol instead of a double product.
+    const double theta_d = (double)cfo_f - (double)cfo_c;
+    const unsigned long long Qp = (unsigned long long)(long long)__builtin_rint(theta_d * WR_TWO_OVER_PI_D * 4611686018427387904.0);
     c32 u16;                                                   // exp(j theta 16)
-    sp_sincos_d(theta_d * 16.0, u16.im, u16.re);
+    {
+        const unsigned long long q16 = Qp * 16ull;
+        sp_sincos_q((uint32_t)(q16 >> 32), (uint32_t)q16, u16.im, u16.re);
+    }
+    unsigned long long ph = Qp * (unsigned long long)(unsigned)(fs + r);
+    const unsigned long long q80 = Qp * 80ull;
     int n_sym = 0, n_bpsc = 1, n_out = 0, enc = 0, psdu_len = 0;
     bool have_signal = false, want_llr = false;
     float snr = 0.0f;
@@ -454,7 +463,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         }
         {   // one rotation by the total offset: base phasor from a double angle, then steps of exp(j theta 16)
             c32 w;
-            sp_sincos_d(theta_d * (double)(off0 + r), w.im, w.re);
+            sp_sincos_q((uint32_t)(ph >> 32), (uint32_t)ph, w.im, w.re);
+            ph += (s == 0) ? (q80 - Qp * 16ull) : q80;          // next symbol starts 64 (s = 0) or 80 samples later
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 c32 xs = act ? cur[j] : c32{ 0.0f, 0.0f };
@@ -498,9 +508,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         // (1) sampling offset: bins (r - 32) + 16 j share the step exp(j t4 16/64)
         {
             double t4 = two_pi * s * 80 * (eps0 + d_er);
+            const float kf = (float)(t4 * (1.0 / 64));          // upstream's double chain up to here, float per bin
             c32 step, q;
-            sp_sincos_small((float)(t4 * 16.0 / 64), step.im, step.re);
-            sp_sincos_small((float)(t4 * (double)(r - 32) / 64), q.im, q.re);
+            sp_sincos_small(kf * 16.0f, step.im, step.re);
+            sp_sincos_small(kf * (float)(r - 32), q.im, q.re);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 X[j] = sp_cmul(X[j], q);

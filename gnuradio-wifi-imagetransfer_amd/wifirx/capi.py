@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwifirx.so")
+LIB_PATH = os.environ.get("WIFIRX_LIB") or os.path.join(_HERE, "libwifirx.so")     # WIFIRX_LIB: A/B builds
 
 ABI_VERSION = 2
 EQ_LS, EQ_LMS, EQ_COMB, EQ_STA = 0, 1, 2, 3

@@ -102,6 +102,30 @@ static inline void sp_sincos_d(double x, float* s, float* c)
     }
 }
 
+/* sine/cosine of a phase given in 2^-62 quarter turns, modulo 2^64 (spec section 4.8): the integer phase of sample
+ * m is Q*m with wrap-around, so the reduction is a shift and the quadrant the two top bits. */
+static inline void sp_sincos_q(uint64_t P, float* s, float* c)
+{
+    uint32_t th = (uint32_t)(P >> 32) + 0x20000000u, tl = (uint32_t)P;     /* + half a quarter turn: round to nearest */
+    unsigned k  = th >> 30;
+    uint32_t uh = (th << 2) | (tl >> 30);                                   /* fraction of the quarter turn, offset 1/2 */
+    int32_t  gh = (int32_t)(uh ^ 0x80000000u);                              /* [-2^31, 2^31) <-> [-1/2, 1/2) quarter turn */
+    float r  = (float)gh * WR_PIO2_2M32;
+    float z  = r * r;
+    float ps = fmaf(z, WR_S3, WR_S2);
+    ps = fmaf(ps, z, WR_S1);
+    float sr = fmaf(ps * z, r, r);
+    float pc = fmaf(z, WR_C3, WR_C2);
+    pc = fmaf(pc, z, WR_C1);
+    float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    switch (k & 3) {
+    case 0:  *s = sr;  *c = cr;  break;
+    case 1:  *s = cr;  *c = -sr; break;
+    case 2:  *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr;  break;
+    }
+}
+
 static inline float sp_atan2(float y, float x)
 {
     float ax = fabsf(x), ay = fabsf(y);
@@ -669,8 +693,10 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     const double eps0 = tag * bw / (2 * M_PI * fc);
     double d_er = 0.0;
     const double theta_d = (double)cfo_f - (double)cfo_c;       /* total derotation, rad/sample */
+    /* ... as an integer phase increment: 2^-62 quarter turns per sample */
+    const uint64_t Qp = (uint64_t)(int64_t)rint(theta_d * WR_TWO_OVER_PI_D * 4611686018427387904.0);
     c32 u16;                                                    /* exp(j theta 16) */
-    sp_sincos_d(theta_d * 16.0, &u16.im, &u16.re);
+    sp_sincos_q(Qp * 16u, &u16.im, &u16.re);
     c32 prev[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
     c32 H[64], G[64];
     memset(H, 0, sizeof H);
@@ -688,12 +714,12 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
         /* sync_short copy + sync_long copy.  Upstream: two float rotations exp(-j cfo_c m), exp(+j cfo_f m)
          * per sample.  Spec (section 4.8): one rotation by the total offset; the phasor of sample m0 + r (r = 0..15)
          * comes from a double angle reduced in double, the samples 16, 32, 48 further on from three
-         * multiplications by the frame's exp(j theta 16). */
+         * multiplications by the frame's exp(j theta 16).  The phase is kept as an exact integer (Q*m mod 2^64). */
         c32 z[64], X[64];
         if (spec) {
             for (int r = 0; r < 16; r++) {
                 float ws, wc;
-                sp_sincos_d(theta_d * (double)(off0 + r), &ws, &wc);
+                sp_sincos_q(Qp * (uint64_t)(off0 + r), &ws, &wc);
                 c32 w = { wc, ws };
                 for (int j = 0; j < 4; j++) {
                     c32 xs = x_at(x, n_samp, t - 16 + off0 + r + 16 * j);
@@ -716,12 +742,13 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
         /* (1) sampling offset compensation.  Spec: bins r-32 + 16 j share the step exp(j t4 16/64) */
         double t4 = 2 * M_PI * s * 80 * (eps0 + d_er);
         if (spec) {
+            const float kf = (float)(t4 * (1.0 / 64));      /* the double chain of upstream up to here, float per bin */
             float ss, sc;
-            sp_sincos((float)(t4 * 16.0 / 64), &ss, &sc);
+            sp_sincos(kf * 16.0f, &ss, &sc);
             c32 step = { sc, ss };
             for (int r = 0; r < 16; r++) {
                 float bs, bc;
-                sp_sincos((float)(t4 * (double)(r - 32) / 64), &bs, &bc);
+                sp_sincos(kf * (float)(r - 32), &bs, &bc);
                 c32 q = { bc, bs };
                 for (int j = 0; j < 4; j++) {
                     X[r + 16 * j] = sp_cmul(X[r + 16 * j], q);
