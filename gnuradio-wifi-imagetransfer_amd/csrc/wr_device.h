@@ -57,28 +57,6 @@ __device__ __forceinline__ void sp_sincos_small(float x, float& s, float& c)
     }
 }
 
-// sine/cosine of a double angle: reduction by pi/2 in double, polynomials in float (spec section 4.1)
-__device__ __forceinline__ void sp_sincos_d(double x, float& s, float& c)
-{
-    double kd = __builtin_rint(x * WR_TWO_OVER_PI_D);
-    int    k  = (int)kd;
-    double rd = __builtin_fma(-kd, WR_PIO2_D_HI, x);
-    rd = __builtin_fma(-kd, WR_PIO2_D_LO, rd);
-    float r  = (float)rd;
-    float z  = r * r;
-    float ps = fma_(z, WR_S3, WR_S2);
-    ps = fma_(ps, z, WR_S1);
-    float sr = fma_(ps * z, r, r);
-    float pc = fma_(z, WR_C3, WR_C2);
-    pc = fma_(pc, z, WR_C1);
-    float cr = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
-    bool  odd = k & 1;
-    float s0 = odd ? cr : sr;
-    float c0 = odd ? sr : cr;
-    s = (k & 2) ? -s0 : s0;
-    c = ((k + 1) & 2) ? -c0 : c0;
-}
-
 // sine/cosine of a phase given in 2^-62 quarter turns modulo 2^64 (spec section 4.8): reduction = shift, quadrant = top bits
 __device__ __forceinline__ void sp_sincos_q(uint32_t p_hi, uint32_t p_lo, float& s, float& c)
 {
@@ -212,12 +190,4 @@ __device__ __forceinline__ float row_suffix16(float v)
     v = dpp_zero<0x108>(v) + v;
     return v;
 }
-// xor-butterfly sum over the 64 lanes (the spec's pairwise tree): every lane ends with the total
-__device__ __forceinline__ float tree_sum64(float v)
-{
-#pragma unroll
-    for (int k = 1; k < 64; k <<= 1) v = v + __shfl_xor(v, k, 64);
-    return v;
-}
-
 }  // namespace wr

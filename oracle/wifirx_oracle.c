@@ -78,30 +78,6 @@ static inline void sp_sincos(float x, float* s, float* c)
     }
 }
 
-/* sine/cosine of a double angle: reduction by pi/2 in double (two fma with a hi/lo split), the
- * polynomials of sp_sincos in float on the reduced argument */
-static inline void sp_sincos_d(double x, float* s, float* c)
-{
-    double kd = rint(x * WR_TWO_OVER_PI_D);
-    int    k  = (int)kd;
-    double rd = fma(-kd, WR_PIO2_D_HI, x);
-    rd = fma(-kd, WR_PIO2_D_LO, rd);
-    float r  = (float)rd;
-    float z  = r * r;
-    float ps = fmaf(z, WR_S3, WR_S2);
-    ps = fmaf(ps, z, WR_S1);
-    float sr = fmaf(ps * z, r, r);
-    float pc = fmaf(z, WR_C3, WR_C2);
-    pc = fmaf(pc, z, WR_C1);
-    float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
-    switch (k & 3) {
-    case 0:  *s = sr;  *c = cr;  break;
-    case 1:  *s = cr;  *c = -sr; break;
-    case 2:  *s = -sr; *c = -cr; break;
-    default: *s = -cr; *c = sr;  break;
-    }
-}
-
 /* sine/cosine of a phase given in 2^-62 quarter turns, modulo 2^64 (spec section 4.8): the integer phase of sample
  * m is Q*m with wrap-around, so the reduction is a shift and the quadrant the two top bits. */
 static inline void sp_sincos_q(uint64_t P, float* s, float* c)
