@@ -90,3 +90,36 @@ def test_config1_kodim01_pieces_through_the_block():
         assert np.array_equal(out[y:y + 10, xx:xx + 10, c:c + 1], piece)
     st = rx.stats()
     assert st["frames_crc_ok"] == 1000
+
+
+def test_two_handles_on_two_threads(orc):
+    """handles are independent (own HIP stream, no global state): two threads, one handle each, concurrently"""
+    import threading
+    from wifirx import capi
+    from helpers import make_slots
+    jobs = []
+    for enc, seed in ((2, 11), (5, 12)):
+        iq, slot_len, tx = make_slots(200, enc, snr_db=25.0, seed=seed)
+        prm = orc.make_params(max_sym=tx.n_sym, llr_bits=6)
+        o = orc.demod_batch(iq, slot_len, prm)
+        jobs.append((iq, slot_len, tx, o))
+    results = [None, None]
+
+    def run(k):
+        iq, slot_len, tx, _ = jobs[k]
+        rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=6)
+        for _ in range(5):
+            results[k] = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=320)
+        rx.close()
+
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        _, _, tx, o = jobs[k]
+        r = results[k]
+        assert np.array_equal(r["idx"], o["idx"]) and np.array_equal(r["llr"], o["llr"])
+        assert ((r["frames"]["flags"] & capi.F_CRC_OK) != 0).all()
+        assert np.array_equal(r["psdu"][:, :294], tx.psdu)
