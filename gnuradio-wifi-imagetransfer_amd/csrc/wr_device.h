@@ -181,6 +181,17 @@ __device__ __forceinline__ float row_prefix16(float v)
     v = dpp_zero<0x118>(v) + v;   // row_shr:8
     return v;
 }
+// maximum over each row of 16 lanes, valid in the row's last lane (lanes shifted in from outside the row keep INT_MIN)
+__device__ __forceinline__ int row_max16(int v)
+{
+#define WR_ROW_MAX_STEP(CTRL) { int o = __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xf, 0xf, false); v = o > v ? o : v; }
+    WR_ROW_MAX_STEP(0x111)   // row_shr:1
+    WR_ROW_MAX_STEP(0x112)   // row_shr:2
+    WR_ROW_MAX_STEP(0x114)   // row_shr:4
+    WR_ROW_MAX_STEP(0x118)   // row_shr:8
+#undef WR_ROW_MAX_STEP
+    return v;
+}
 // inclusive suffix sum: v[i] += v[i+k]
 __device__ __forceinline__ float row_suffix16(float v)
 {

@@ -175,32 +175,39 @@ __device__ __forceinline__ bool preamble_sync(const float2* __restrict__ x, long
         mag[pass] = fma_(ai, ai, ar * ar);
     }
     __builtin_amdgcn_wave_barrier();
+    // The four largest |corr|^2 in turn, lowest lag first among equal values.  |corr|^2 >= +0, so its bit pattern
+    // orders like a signed integer; NaN and already-taken entries are -1 ("invalid").  Per round: one integer
+    // max over the wave (DPP inside the rows, the four row results through SGPRs), then the first lag that holds it.
+    int km[5];
+#pragma unroll
+    for (int pass = 0; pass < 5; pass++) km[pass] = (mag[pass] >= 0.0f) ? (int)__float_as_uint(mag[pass]) : -1;
     int top_off[4];
     c32 top_val[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        unsigned long long key = 0;
+        int m = km[0];
 #pragma unroll
-        for (int pass = 0; pass < 5; pass++) {
-            int i = pass * 64 + lane;
-            unsigned long long kk = ((unsigned long long)__float_as_uint(mag[pass]) << 32) |
-                                    (unsigned)(0xffffffffu - (unsigned)i);
-            bool valid = mag[pass] >= 0.0f;
-            if (valid && kk > key) key = kk;
-        }
-#pragma unroll
-        for (int k = 1; k < 64; k <<= 1) {
-            unsigned long long o = __shfl_xor(key, k, 64);
-            key = o > key ? o : key;
-        }
-        int w = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-        int wl = w & 63, wp = w >> 6;
+        for (int pass = 1; pass < 5; pass++) m = km[pass] > m ? km[pass] : m;
+        m = row_max16(m);
+        const int m0 = __builtin_amdgcn_readlane(m, 15), m1 = __builtin_amdgcn_readlane(m, 31);
+        const int m2 = __builtin_amdgcn_readlane(m, 47), m3 = __builtin_amdgcn_readlane(m, 63);
+        const int m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
+        const int best = m01 > m23 ? m01 : m23;
+        int w = -1;
         c32 val = { 0.0f, 0.0f };
+        if (best >= 0) {
 #pragma unroll
-        for (int pass = 0; pass < 5; pass++) {
-            if (pass == wp) {
-                val = bcast(corr[pass], wl);
-                if (lane == wl) mag[pass] = -1.0f;
+            for (int pass = 4; pass >= 0; pass--) {
+                const uint64_t hit = __ballot(km[pass] == best);
+                if (hit) w = pass * 64 + (int)__builtin_ctzll(hit);
+            }
+            const int wl = w & 63, wp = w >> 6;
+#pragma unroll
+            for (int pass = 0; pass < 5; pass++) {
+                if (pass == wp) {
+                    val = bcast(corr[pass], wl);
+                    if (lane == wl) km[pass] = -1;
+                }
             }
         }
         top_off[r] = w;
@@ -467,7 +474,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             ph += (s == 0) ? (q80 - Qp * 16ull) : q80;          // next symbol starts 64 (s = 0) or 80 samples later
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                c32 xs = act ? cur[j] : c32{ 0.0f, 0.0f };
+#if WR_PREFETCH
+                c32 xs = act ? cur[j] : c32{ 0.0f, 0.0f };       // prefetched regardless of act
+#else
+                c32 xs = cur[j];                                   // rows without a symbol loaded zeros above
+#endif
                 v[j] = sp_cmul(xs, w);
                 w = sp_cmul(w, u16);
             }
@@ -505,18 +516,19 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         // stage-3 output q3 is sub-carrier k = r + 16 q3, i.e. shifted bin i = r + 16 ((q3 + 2) & 3)
         c32 X[4] = { v[2], v[3], v[0], v[1] };
 
-        // (1) sampling offset: bins (r - 32) + 16 j share the step exp(j t4 16/64)
+        // (1) sampling offset (spec rule 9)
         {
             double t4 = two_pi * s * 80 * (eps0 + d_er);
             const float kf = (float)(t4 * (1.0 / 64));          // upstream's double chain up to here, float per bin
-            c32 step, q;
-            sp_sincos_small(kf * 16.0f, step.im, step.re);
-            sp_sincos_small(kf * (float)(r - 32), q.im, q.re);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                X[j] = sp_cmul(X[j], q);
-                q = sp_cmul(q, step);
-            }
+            // b = phasor of bin r + 16; lane 0 of the row holds exp(-j kf 16), whose conjugate is the step
+            c32 b;
+            sp_sincos_small(kf * (float)(r - 16), b.im, b.re);
+            const c32 b0 = row_bcast<0>(b), step = { b0.re, -b0.im };
+            const c32 q0 = sp_cmul(b, b0), q2 = sp_cmul(b, step), q3 = sp_cmul(q2, step);
+            X[0] = sp_cmul(X[0], q0);
+            X[1] = sp_cmul(X[1], b);
+            X[2] = sp_cmul(X[2], q2);
+            X[3] = sp_cmul(X[3], q3);
         }
         // (2) pilots: bins 11, 25, 39, 53 = (lane 11, j 0), (lane 9, j 1), (lane 7, j 2), (lane 5, j 3)
         c32 X11 = row_bcast<11>(X[0]), X25 = row_bcast<9>(X[1]), X39 = row_bcast<7>(X[2]), X53 = row_bcast<5>(X[3]);

@@ -715,21 +715,24 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
         }
         if (spec) fft64_spec(z, X); else fft64_libm(z, X);
 
-        /* (1) sampling offset compensation.  Spec: bins r-32 + 16 j share the step exp(j t4 16/64) */
+        /* (1) sampling offset compensation */
         double t4 = 2 * M_PI * s * 80 * (eps0 + d_er);
         if (spec) {
+            /* Spec rule 9: b(r) = exp(j kf (r - 16)) is the phasor of bin r + 16; the step between bins 16 apart is
+             * conj(b(0)) = exp(j kf 16); bins r, r + 32, r + 48 take b(r) b(0), b(r) step, (b(r) step) step. */
             const float kf = (float)(t4 * (1.0 / 64));      /* the double chain of upstream up to here, float per bin */
-            float ss, sc;
-            sp_sincos(kf * 16.0f, &ss, &sc);
-            c32 step = { sc, ss };
+            float s0, c0;
+            sp_sincos(kf * (float)(0 - 16), &s0, &c0);
+            const c32 b0 = { c0, s0 }, step = { c0, -s0 };
             for (int r = 0; r < 16; r++) {
                 float bs, bc;
-                sp_sincos(kf * (float)(r - 32), &bs, &bc);
-                c32 q = { bc, bs };
-                for (int j = 0; j < 4; j++) {
-                    X[r + 16 * j] = sp_cmul(X[r + 16 * j], q);
-                    q = sp_cmul(q, step);
-                }
+                sp_sincos(kf * (float)(r - 16), &bs, &bc);
+                const c32 b = { bc, bs };
+                const c32 q0 = sp_cmul(b, b0), q2 = sp_cmul(b, step), q3 = sp_cmul(q2, step);
+                X[r]      = sp_cmul(X[r], q0);
+                X[r + 16] = sp_cmul(X[r + 16], b);
+                X[r + 32] = sp_cmul(X[r + 32], q2);
+                X[r + 48] = sp_cmul(X[r + 48], q3);
             }
         } else {
             for (int i = 0; i < 64; i++) {
