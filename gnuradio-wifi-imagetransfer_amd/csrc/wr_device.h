@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #define WR_TABLE_QUAL __device__
+#define WR_WANT_T4_TABLE
 #include "wifirx_tables.h"
 
 namespace wr {
@@ -158,6 +159,11 @@ __device__ __forceinline__ c32 sp_conj_mul(c32 a, c32 b)
 __device__ __forceinline__ c32 cadd(c32 a, c32 b) { return { a.re + b.re, a.im + b.im }; }
 __device__ __forceinline__ c32 csub(c32 a, c32 b) { return { a.re - b.re, a.im - b.im }; }
 __device__ __forceinline__ c32 cneg(c32 a) { return { -a.re, -a.im }; }
+// a with the sign bits of both parts xor-ed with m (m = 0 or 0x80000000: a or -a)
+__device__ __forceinline__ c32 cflip(c32 a, uint32_t m)
+{
+    return { __uint_as_float(__float_as_uint(a.re) ^ m), __uint_as_float(__float_as_uint(a.im) ^ m) };
+}
 
 // ---- cross-lane helpers (wave64) --------------------------------------------------------------
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }

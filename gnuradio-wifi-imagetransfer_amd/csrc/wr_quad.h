@@ -271,7 +271,8 @@ __device__ __forceinline__ void bfly4_reg(c32& a, c32& b, c32& c, c32& d)
 template <int LANE>
 __device__ __forceinline__ float row_bcast(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + LANE, 0xf, 0xf, false));
+    // every lane is written (row_newbcast, full masks): mov_dpp leaves the previous value of the destination undefined
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x150 + LANE, 0xf, 0xf, false));
 }
 template <int LANE>
 __device__ __forceinline__ c32 row_bcast(c32 v) { return { row_bcast<LANE>(v.re), row_bcast<LANE>(v.im) }; }
@@ -447,26 +448,32 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         }
         if (!__any(act)) break;
 
-        // ---- samples r + 16 j of the symbol, two derotations each (sync_short / sync_long copy) ----
+        // ---- samples r + 16 j of the symbol (rows without a symbol get zeros) ----
         c32 v[4], cur[4];
         {
             const int offn = fs + (s + 1 < 2 ? 64 * (s + 1) : 128 + 80 * (s - 1) + 16);
+#if WR_PREFETCH
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-#if WR_PREFETCH
                 cur[j] = nx[j];
                 nx[j] = load_y(xb, offn + r + 16 * j, m_lo, m_hi);
-#else
-                (void)offn;
-                if (lo_zero) {          // act => off0 + 63 < L <= m_hi: every sample of the symbol is in range
-                    float2 t = make_float2(0.0f, 0.0f);
-                    if (act) t = xb[off0 + r + 16 * j];
-                    cur[j] = { t.x, t.y };
-                } else {
-                    cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
-                }
-#endif
             }
+#else
+            (void)offn;
+            if (lo_zero) {              // act => off0 + 63 < L <= m_hi: every sample of the symbol is in range
+                float2 t[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+                if (act) {
+                    const float2* p = xb + (off0 + r);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) t[j] = p[16 * j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) cur[j] = { t[j].x, t[j].y };
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
+            }
+#endif
         }
         {   // one rotation by the total offset: base phasor from a double angle, then steps of exp(j theta 16)
             c32 w;
@@ -518,8 +525,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 
         // (1) sampling offset (spec rule 9)
         {
-            double t4 = two_pi * s * 80 * (eps0 + d_er);
-            const float kf = (float)(t4 * (1.0 / 64));          // upstream's double chain up to here, float per bin
+            // upstream's double chain 2 pi s 80 (eps0 + d_er) / 64, float per bin; the factor that depends on s
+            // alone comes from a table (the division by 64 is exact, so it commutes with the product)
+            const float kf = (float)(WR_T4_64[s] * (eps0 + d_er));
             // b = phasor of bin r + 16; lane 0 of the row holds exp(-j kf 16), whose conjugate is the step
             c32 b;
             sp_sincos_small(kf * (float)(r - 16), b.im, b.re);
@@ -532,21 +540,24 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         }
         // (2) pilots: bins 11, 25, 39, 53 = (lane 11, j 0), (lane 9, j 1), (lane 7, j 2), (lane 5, j 3)
         c32 X11 = row_bcast<11>(X[0]), X25 = row_bcast<9>(X[1]), X39 = row_bcast<7>(X[2]), X53 = row_bcast<5>(X[3]);
-        bool pneg = (s >= 2) && (WR_POLARITY[(s - 2) % 127] < 0);
+        // polarity of symbol s - 2 as a sign-bit mask (wave-uniform: scalar registers): negating = xor
+        uint32_t sgn = 0;
+        if (s >= 2) {
+            const int pk = (s - 2) % 127;
+            const uint64_t bits = pk < 64 ? (WR_POLARITY_NEG_LO >> pk) : (WR_POLARITY_NEG_HI >> (pk - 64));
+            sgn = (uint32_t)(bits & 1ull) << 31;
+        }
         c32 S;
         if (s < 2) S = cadd(cadd(csub(X11, X25), X39), X53);
-        else {
-            S = csub(cadd(cadd(X11, X39), X25), X53);
-            if (pneg) S = cneg(S);
-        }
+        else       S = cflip(csub(cadd(cadd(X11, X39), X25), X53), sgn);
         // (3) residual offset estimate
         c32 cur0, cur1, cur2, cur3;
         if (s < 2) { cur0 = X11; cur1 = cneg(X25); cur2 = X39; cur3 = X53; }
         else {
-            cur0 = pneg ? cneg(X11) : X11;
-            cur1 = pneg ? cneg(X25) : X25;
-            cur2 = pneg ? cneg(X39) : X39;
-            cur3 = pneg ? X53 : cneg(X53);
+            cur0 = cflip(X11, sgn);
+            cur1 = cflip(X25, sgn);
+            cur2 = cflip(X39, sgn);
+            cur3 = cflip(X53, sgn ^ 0x80000000u);
         }
         double er = 0.0;
         if (s >= 2) {
@@ -618,7 +629,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 carrier[j] = carrier0[j];
                 asm volatile("" : "+v"(carrier[j]));     // keeps base + carrier out of loop-invariant registers
                 Y[j] = { 0.0f, 0.0f };
-                if (carrier[j] >= 0) {
+                // LS: every bin is multiplied (G = 0 on unused bins; pilot bins are never stored)
+                if (!LMS || carrier[j] >= 0) {
                     const float2 g0 = Hl[64 * j];
                     if (LMS) {
                         const float d = fma_(g0.y, g0.y, g0.x * g0.x);
