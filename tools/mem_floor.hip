@@ -1,0 +1,155 @@
+// Memory floor of wr::demod_batch_kernel: the same global loads and stores, in the same order, by waves organised
+// the same way (four slots per wave, lane r of a row holds bins r + 16 j), with no arithmetic in between.
+// The time of this kernel is what the memory system alone needs for config 2's access pattern; the distance of the
+// real kernel from it is what arithmetic and imperfect overlap cost.  
+//   hipcc --offload-arch=gfx950 -O3 tools/mem_floor.hip -o tools/mem_floor.bin && tools/mem_floor.bin [n_slots]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+__global__ __launch_bounds__(256, 4) void pattern(const float2* __restrict__ x, uint32_t n_slots, int slot_len, int n_sym,
+                                                  uint8_t* __restrict__ idx, float2* __restrict__ llr, float* sink,
+                                                  int do_preamble, int do_loads, int do_stores)
+{
+    const int lane = threadIdx.x & 63, row = lane >> 4, r = lane & 15;
+    const uint32_t slot = ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 4) + row;
+    if (slot >= n_slots) return;
+    const float2* xs = x + (size_t)slot * slot_len;
+    float acc = 0.0f;
+    if (do_preamble) {
+        // detection: tiles of 64 samples (lane = sample) up to the trigger (~ sample 200), each sample and the one 16 back;
+        // then 383 samples from the trigger - 16 on.  Done per slot by the whole wave, as the kernel does.
+        for (int f = 0; f < 4; f++) {
+            const float2* xf = x + (size_t)(slot - row + f) * slot_len;
+            if (slot - row + f >= n_slots) break;
+            for (int n0 = 0; n0 < 256; n0 += 64) {
+                float2 a = xf[n0 + lane], b = xf[n0 + lane >= 16 ? n0 + lane - 16 : 0];
+                acc += a.x + b.y;
+            }
+            for (int p = 0; p < 6; p++) { float2 a = xf[176 + 64 * p + lane]; acc += a.x; }
+        }
+    }
+    int carrier[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = r + 16 * j;
+        const bool data = (i >= 6 && i <= 58 && i != 11 && i != 25 && i != 32 && i != 39 && i != 53);
+        carrier[j] = data ? (i - 6 - (i > 11) - (i > 25) - (i > 32) - (i > 39) - (i > 53)) : -1;
+    }
+    uint8_t* ip = idx + (size_t)slot * n_sym * 48;
+    float2* lp = llr + (size_t)slot * n_sym * 48;
+    for (int s = 0; s < n_sym + 3; s++) {
+        const int off = 352 + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
+        float2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            v[j] = make_float2((float)s, (float)j);
+            if (do_loads) v[j] = xs[off + r + 16 * j];
+        }
+        if (s >= 3) {
+            const int q = s - 3;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (carrier[j] < 0 || !do_stores) { acc += v[j].x; continue; }
+                const unsigned o = (unsigned)(q * 48 + carrier[j]);
+                ip[o] = (uint8_t)((v[j].x > 0.0f) | ((v[j].y > 0.0f) << 1));
+                lp[o] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc += v[j].x + v[j].y;
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+// store-pattern variants: mode 0 = the kernel's pattern (per bin: one byte + one float2, rows interleaved),
+// 1 = LLR only in that pattern, 2 = idx only in that pattern, 3 = LLR as full lines (lane l of the wave writes
+// 16 B + 8 B of the 1536 contiguous... per-row 384 B: lanes 0..23 of a row-major order), 4 = idx as dwords (12 lanes per row),
+// 5 = 3 + 4 together
+__global__ __launch_bounds__(256, 4) void store_modes(uint32_t n_slots, int n_sym, uint8_t* __restrict__ idx,
+                                                     float2* __restrict__ llr, int mode)
+{
+    const int lane = threadIdx.x & 63, row = lane >> 4, r = lane & 15;
+    const uint32_t slot0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    const uint32_t slot = slot0 + row;
+    if (slot0 + 3 >= n_slots) return;
+    int carrier[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = r + 16 * j;
+        const bool data = (i >= 6 && i <= 58 && i != 11 && i != 25 && i != 32 && i != 39 && i != 53);
+        carrier[j] = data ? (i - 6 - (i > 11) - (i > 25) - (i > 32) - (i > 39) - (i > 53)) : -1;
+    }
+    uint8_t* ip = idx + (size_t)slot * n_sym * 48;
+    float2* lp = llr + (size_t)slot * n_sym * 48;
+    for (int q = 0; q < n_sym; q++) {
+        const float2 v = make_float2((float)q, (float)lane);
+        if (mode <= 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (carrier[j] < 0) continue;
+                const unsigned o = (unsigned)(q * 48 + carrier[j]);
+                if (mode != 1) ip[o] = (uint8_t)(q + j);
+                if (mode != 2) lp[o] = v;
+            }
+        }
+        if (mode == 3 || mode == 5) {
+            // 4 rows x 384 B: 96 chunks of 16 B; lane l writes chunks l and (l < 32 ? 64 + l : none)
+            for (int c = lane; c < 96; c += 64) {
+                const int rw = c / 24, k = c % 24;
+                float4* dst = reinterpret_cast<float4*>(llr + ((size_t)(slot0 + rw) * n_sym + q) * 48) + k;
+                *dst = make_float4(v.x, v.y, v.x, v.y);
+            }
+        }
+        if (mode == 4 || mode == 5) {
+            if (r < 12) reinterpret_cast<uint32_t*>(idx + ((size_t)slot * n_sym + q) * 48)[r] = 0x01020304u * (unsigned)q;
+        }
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const uint32_t n_slots = argc > 1 ? (uint32_t)atol(argv[1]) : 1000000u;
+    const int slot_len = 4608, n_sym = 50;
+    float2 *x, *llr; uint8_t* idx; float* o;
+    if (hipMalloc(&x, (size_t)n_slots * slot_len * sizeof(float2)) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    (void)hipMalloc(&llr, (size_t)n_slots * n_sym * 48 * sizeof(float2));
+    (void)hipMalloc(&idx, (size_t)n_slots * n_sym * 48);
+    (void)hipMalloc(&o, 4);
+    (void)hipMemset(x, 0x3c, (size_t)n_slots * slot_len * sizeof(float2));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const char* names[4] = { "loads+stores+preamble", "loads+stores", "loads only", "stores only" };
+    const int cfg[4][3] = { { 1, 1, 1 }, { 0, 1, 1 }, { 0, 1, 0 }, { 0, 0, 1 } };
+    for (int c = 0; c < 4; c++) {
+        float best = 1e9f;
+        for (int it = 0; it < 5; it++) {
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(pattern, dim3((n_slots + 15) / 16), dim3(256), 0, 0, x, n_slots, slot_len, n_sym, idx, llr, o,
+                               cfg[c][0], cfg[c][1], cfg[c][2]);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            if (it > 0 && ms < best) best = ms;
+        }
+        const double rd = (double)n_slots * ((cfg[c][1] ? 53.0 * 64 * 8 : 0) + (cfg[c][0] ? 640.0 * 8 : 0));
+        const double wr = cfg[c][2] ? (double)n_slots * n_sym * 48 * 9 : 0;
+        printf("%-24s %8.3f ms   %.1f GB moved by lanes -> %.2f TB/s\n", names[c], best, (rd + wr) / 1e9, (rd + wr) / best / 1e9);
+    }
+    for (int mode = 0; mode < 6; mode++) {
+        float best = 1e9f;
+        for (int it = 0; it < 4; it++) {
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(store_modes, dim3((n_slots + 15) / 16), dim3(256), 0, 0, n_slots, n_sym, idx, llr, mode);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            if (it > 0 && ms < best) best = ms;
+        }
+        const double wr = (double)n_slots * n_sym * 48 * ((mode == 0 || mode == 5) ? 9 : (mode == 1 || mode == 3) ? 8 : 1);
+        printf("store mode %d: %8.3f ms  %.1f GB -> %.2f TB/s\n", mode, best, wr / 1e9, wr / best / 1e9);
+    }
+    return 0;
+}
