@@ -71,6 +71,7 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    local_rank %= max(1, torch.cuda.device_count())      # a launcher that shows every rank one device only
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
