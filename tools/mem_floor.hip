@@ -49,6 +49,16 @@ __global__ __launch_bounds__(256, 4) void pattern(const float2* __restrict__ x, 
         }
         if (s >= 3) {
             const int q = s - 3;
+            if (do_stores == 2) {      // whole lines: 96 chunks of 16 B of LLRs per wave and symbol, 12 dwords of decisions per row
+                const uint32_t slot0 = slot - row;
+                for (int c = lane; c < 96; c += 64) {
+                    const int rw = c / 24, k = c % 24;
+                    float4* dst = reinterpret_cast<float4*>(llr + ((size_t)(slot0 + rw) * n_sym + q) * 48) + k;
+                    *dst = make_float4(v[0].x, v[1].y, v[2].x, v[3].y);
+                }
+                if (r < 12) reinterpret_cast<uint32_t*>(ip + q * 48)[r] = __float_as_uint(v[0].x + v[1].x + v[2].y + v[3].y);
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (carrier[j] < 0 || !do_stores) { acc += v[j].x; continue; }
@@ -121,9 +131,10 @@ int main(int argc, char** argv)
     (void)hipMemset(x, 0x3c, (size_t)n_slots * slot_len * sizeof(float2));
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    const char* names[4] = { "loads+stores+preamble", "loads+stores", "loads only", "stores only" };
-    const int cfg[4][3] = { { 1, 1, 1 }, { 0, 1, 1 }, { 0, 1, 0 }, { 0, 0, 1 } };
-    for (int c = 0; c < 4; c++) {
+    const char* names[6] = { "loads+stores+preamble", "loads+stores", "loads only", "stores only",
+                             "loads+line stores+preamble", "loads+line stores" };
+    const int cfg[6][3] = { { 1, 1, 1 }, { 0, 1, 1 }, { 0, 1, 0 }, { 0, 0, 1 }, { 1, 1, 2 }, { 0, 1, 2 } };
+    for (int c = 0; c < 6; c++) {
         float best = 1e9f;
         for (int it = 0; it < 5; it++) {
             (void)hipEventRecord(e0, 0);
@@ -136,7 +147,7 @@ int main(int argc, char** argv)
         }
         const double rd = (double)n_slots * ((cfg[c][1] ? 53.0 * 64 * 8 : 0) + (cfg[c][0] ? 640.0 * 8 : 0));
         const double wr = cfg[c][2] ? (double)n_slots * n_sym * 48 * 9 : 0;
-        printf("%-24s %8.3f ms   %.1f GB moved by lanes -> %.2f TB/s\n", names[c], best, (rd + wr) / 1e9, (rd + wr) / best / 1e9);
+        printf("%-28s %8.3f ms   %.1f GB moved by lanes -> %.2f TB/s\n", names[c], best, (rd + wr) / 1e9, (rd + wr) / best / 1e9);
     }
     for (int mode = 0; mode < 6; mode++) {
         float best = 1e9f;
