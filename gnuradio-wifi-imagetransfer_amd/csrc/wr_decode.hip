@@ -2,13 +2,18 @@
 // (gnu_radio/IRS_AP.py:272,291-292): demap indices to bits, de-interleave, de-puncture, Viterbi
 // K=7 (133,171), descramble, CRC-32.
 //
-// One wavefront decodes 64 frames, lane <-> frame.  Every lane keeps the 64 path metrics of its own
-// frame in 64 VGPRs and runs the add-compare-select of all 32 butterflies of a trellis step as
-// straight-line code (no cross-lane traffic at all); metrics are updated in place, which rotates the
-// state <-> register map by one bit per step, so the code is unrolled over the 6 steps after which the
-// map is the identity again (all rates have n_data % 12 == 0).  The 64 survivor bits of a step are
-// shifted into two VGPRs by v_addc (carry-in = the compare result) and stored as one coalesced
-// 512-byte row per wave and step; traceback, descrambling and the CRC then run per lane as well.
+// One wavefront decodes 128 frames: lane l owns frames base + l ("A", low halves) and base + 64 + l ("B", high
+// halves).  The 64 path metrics of both frames live in 64 VGPRs as packed 16-bit pairs, and the
+// add-compare-select of all 32 butterflies of a trellis step is straight-line packed arithmetic
+// (v_pk_add_u16 / v_pk_min_u16 / v_pk_sub_i16: one instruction works on both frames, no cross-lane traffic);
+// metrics are updated in place, which rotates the state <-> register map by one bit per step, so the code is
+// unrolled over the 6 steps after which the map is the identity again (all rates have n_data % 12 == 0).
+// The survivor bit of a state is the sign of (candidate 1 - candidate 0), shifted into a packed accumulator by
+// v_pk_lshrrev_b16 + v_pk_mad_u16; the 64 bits per frame and step leave as one 16-byte store per lane.
+// 16-bit metrics: the start penalty of the states != 0 only has to outlast the first six steps (from then on every
+// state has a survivor that started in state 0), and the common minimum is subtracted every 120 steps, so values
+// stay far below 2^15 and the signed difference orders them; decisions depend on differences only.
+// Traceback, descrambling and the CRC run per lane, for its two frames.
 //
 // The received coded bits are gathered beforehand by the whole wave for one frame at a time
 // (lane <-> trellis step: de-puncture + de-interleave + bit extraction from the hard decisions) into
@@ -25,15 +30,11 @@
 
 namespace wr {
 
-#ifndef WR_DEC_ASM
-#define WR_DEC_ASM 1
-#endif
 #ifndef WR_DEC_WAVES_PER_SIMD
 #define WR_DEC_WAVES_PER_SIMD 4
 #endif
 #define WR_DEC_CHUNK      60                   // trellis steps per gathered mask word (10 groups of 6)
-#define WR_DEC_SEG_CHUNKS 4                    // chunks gathered per segment: 240 steps (8 KB of LDS per wave)
-#define WR_DEC_LDS_WORDS  (WR_DEC_SEG_CHUNKS * 4 * 64)   // per wave, 8-byte words: [chunk][A1,AV,B1,BV][frame]
+#define WR_DEC_LDS_WORDS  (4 * WR_DECODE_FRAMES_PER_WAVE)   // per wave, 8-byte words: [A1,AV,B1,BV][frame] of the current chunk
 
 // the coded bit at position `ci` of the de-punctured stream of a frame: 0/1, or 2 when punctured.
 // Rate parameters are template constants: every division below is by a compile-time constant.
@@ -78,56 +79,84 @@ __device__ __forceinline__ void gather_chunk(const uint8_t* __restrict__ fidx, i
 constexpr __host__ __device__ int rotr6(int s, int p) { return ((s >> p) | (s << (6 - p))) & 63; }
 constexpr __host__ __device__ int parity_of(int v) { return __builtin_popcount(v) & 1; }
 
-// new = min(c0, c1), decision = (c1 < c0) shifted into `word` (word = 2*word + decision)
-__device__ __forceinline__ int acs_one(int c0, int c1, uint32_t& word)
+// ---- packed 16-bit arithmetic (both halves at once; the compiler may schedule these freely) ----
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { uint32_t r; asm volatile("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { uint32_t r; asm volatile("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { uint32_t r; asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// acc = 2 * acc + (d < 0) per half; k15 = 0x000f000f, k2 = 0x00020002
+__device__ __forceinline__ uint32_t pk_push_sign(uint32_t acc, uint32_t d, uint32_t k15, uint32_t k2)
 {
-#if WR_DEC_ASM
-    uint32_t w = word;
-    int m;
-    uint64_t cc;
-    asm("v_cmp_lt_i32 %2, %4, %5\n\t"
-        "v_cndmask_b32 %0, %5, %4, %2\n\t"
-        "v_addc_co_u32 %1, %2, %3, %3, %2"
-        : "=&v"(m), "=v"(w), "=&s"(cc)
-        : "v"(w), "v"(c1), "v"(c0));
-    word = w;
-    return m;
-#else
-    const bool d = c1 < c0;
-    word = word + word + (uint32_t)d;
-    return d ? c1 : c0;
-#endif
+    uint32_t t, r;
+    asm volatile("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(t) : "v"(k15), "v"(d));
+    asm volatile("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(k2), "v"(t));
+    return r;
 }
 
-// one trellis step at register phase P: logical state s lives in pm[rotr6(s, P)].
-// M[a][b]: branch metric of a transition whose expected coded pair is (a, b).
+// one trellis step at register phase P: logical state s lives in pm[rotr6(s, P)] (low half: frame A, high: frame B).
+// M[a][b]: packed branch metrics of a transition whose expected coded pair is (a, b).
+// acc[k]: survivor bits of the states 16k..16k+15, first state in the top bit of each half.
 template <int P>
-__device__ __forceinline__ void acs_step(int (&pm)[64], const int (&M)[2][2], uint32_t& dlo, uint32_t& dhi)
+__device__ __forceinline__ void acs_step(uint32_t (&pm)[64], const uint32_t (&M)[2][2], uint32_t (&acc)[4],
+                                         uint32_t k15, uint32_t k2)
 {
-    uint32_t acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // acc[k]: states 8k..8k+7, first state in the top bit
-    // logical order 0..63 so that the survivor bit of state s ends at bit (31 - s%32) of dlo (s<32) / dhi
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[k] = 0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
-        constexpr int dummy = 0; (void)dummy;
         const int a = parity_of((j << 1) & 0155), b = parity_of((j << 1) & 0117);
-        const int m = M[a][b], mb = M[a ^ 1][b ^ 1];
+        const uint32_t m = M[a][b], mb = M[a ^ 1][b ^ 1];
         const int r0 = rotr6(j, P), r1 = rotr6(j + 32, P);
-        const int p0 = pm[r0], p1 = pm[r1];
-        uint32_t& w = acc[j >> 2];
-        // state 2j (input bit 0): from j with m, from j+32 with mb;  state 2j+1: metrics swapped
-        const int n0 = acs_one(p0 + m, p1 + mb, w);
-        const int n1 = acs_one(p0 + mb, p1 + m, w);
-        pm[r0] = n0;      // = register of logical state 2j at phase P+1
-        pm[r1] = n1;      // = register of logical state 2j+1 at phase P+1
+        const uint32_t p0 = pm[r0], p1 = pm[r1];
+        // state 2j (input bit 0): from j with m (candidate 0), from j+32 with mb (candidate 1);  state 2j+1: metrics swapped
+        const uint32_t c00 = pk_add(p0, m), c01 = pk_add(p1, mb), c10 = pk_add(p0, mb), c11 = pk_add(p1, m);
+        uint32_t& w = acc[j >> 3];
+        w = pk_push_sign(w, pk_sub(c01, c00), k15, k2);      // candidate 1 < candidate 0: survivor from j+32
+        w = pk_push_sign(w, pk_sub(c11, c10), k15, k2);
+        pm[r0] = pk_min(c00, c01);      // = register of logical state 2j at phase P+1
+        pm[r1] = pk_min(c10, c11);      // = register of logical state 2j+1 at phase P+1
     }
-    dlo = (acc[0] << 24) | (acc[1] << 16) | (acc[2] << 8) | acc[3];
-    dhi = (acc[4] << 24) | (acc[5] << 16) | (acc[6] << 8) | acc[7];
 }
 
 __device__ __forceinline__ uint32_t crc32_bit(uint32_t c, uint32_t bit)
 {
     uint32_t x = (c ^ bit) & 1u;
     return (c >> 1) ^ (0xedb88320u & (0u - x));
+}
+
+// descramble (x^7+x^4+1, state from the first 7 decoded bits), bytes, CRC-32 of one frame; db = its decoded words
+__device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, int psdu_len, uint8_t* __restrict__ psdu,
+                                             wifirx_frame* __restrict__ rec, uint32_t flags)
+{
+    uint32_t w0 = db[0];
+    int state = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) state |= (int)((w0 >> i) & 1) << (6 - i);
+    // positions 7..15 belong to the SERVICE field: advance the scrambler
+    for (int i = 7; i < 16; i++) {
+        int fb = ((state >> 6) ^ (state >> 3)) & 1;
+        state = ((state << 1) & 0x7e) | fb;
+    }
+    uint32_t crc = 0xffffffffu;
+    uint32_t cur = w0;
+    int wi = 0;
+    for (int b = 0; b < psdu_len; b++) {
+        uint32_t byte = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = 16 + 8 * b + k;
+            if ((i >> 5) != wi) { wi = i >> 5; cur = db[(size_t)wi * 128]; }
+            const uint32_t fb = (uint32_t)(((state >> 6) ^ (state >> 3)) & 1);
+            state = ((state << 1) & 0x7e) | (int)fb;
+            const uint32_t d = ((cur >> (i & 31)) & 1u) ^ fb;
+            byte |= d << k;
+            crc = crc32_bit(crc, d);
+        }
+        psdu[b] = (uint8_t)byte;
+    }
+    crc = ~crc;
+    uint32_t fl = flags | WIFIRX_F_DECODED;
+    if (psdu_len >= 4 && crc == 558161692u) fl |= WIFIRX_F_CRC_OK; else fl &= ~WIFIRX_F_CRC_OK;
+    rec->flags = fl;
 }
 
 __global__ __launch_bounds__(256, WR_DEC_WAVES_PER_SIMD)
@@ -142,167 +171,189 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
     if (wave >= n_waves_total) return;
     uint64_t* lds = lds_all[wv];
     const size_t n_data_cap = n_steps_cap;               // trellis steps the scratch slice of a wave holds
-    uint64_t* surv = reinterpret_cast<uint64_t*>(scratch + (size_t)wave * scratch_stride);   // [step][lane]
-    uint32_t* dbits = reinterpret_cast<uint32_t*>(surv + n_data_cap * 64);                   // [word][lane]
+    uint32_t* surv = reinterpret_cast<uint32_t*>(scratch + (size_t)wave * scratch_stride);   // [step][lane][4 pieces]
+    uint32_t* dbits = surv + n_data_cap * 256;                                               // [word][A/B][lane]
+    uint64_t* masks = reinterpret_cast<uint64_t*>(dbits + (n_data_cap / 32 + 2) * WR_DECODE_FRAMES_PER_WAVE);   // [chunk][4][frame]
+    const uint32_t k15 = 0x000f000fu, k2 = 0x00020002u, k1 = 0x00010001u;
 
     const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
 
-    for (uint32_t base = wave * 64; base < n_slots; base += n_waves_total * 64) {
-        // ---- my frame ----
-        const uint32_t slot = base + lane;
-        wifirx_frame fr;
-        fr.flags = 0; fr.encoding = 0; fr.psdu_len = 0;
-        if (slot < n_slots) fr = frames[slot];
-        const int enc = fr.encoding & 7, psdu_len = fr.psdu_len;
-        const int n_dbps = ndbps_tab[enc];
-        const int n_sym = (16 + 8 * psdu_len + 6 + n_dbps - 1) / n_dbps;
-        const bool valid = slot < n_slots && (fr.flags & WIFIRX_F_COMPLETE) && psdu_len <= (int)psdu_stride &&
-                           psdu_len <= WIFIRX_MAX_PSDU && n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym &&
-                           (uint32_t)(n_sym * n_dbps) <= n_steps_cap;
-        const int n_data = valid ? n_sym * n_dbps : 0;          // multiple of 12
-        int n_max = n_data;
+    for (uint32_t base = wave * WR_DECODE_FRAMES_PER_WAVE; base < n_slots; base += n_waves_total * WR_DECODE_FRAMES_PER_WAVE) {
+        // ---- my two frames ----
+        int enc[2], n_data[2];
+        int n_max = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t slot = base + 64 * h + lane;
+            uint32_t flags = 0;
+            int len = 0;
+            enc[h] = 0;
+            if (slot < n_slots) { flags = frames[slot].flags; enc[h] = frames[slot].encoding & 7; len = frames[slot].psdu_len; }
+            const int n_dbps = ndbps_tab[enc[h]];
+            const int n_sym = (16 + 8 * len + 6 + n_dbps - 1) / n_dbps;
+            const bool ok = slot < n_slots && (flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride &&
+                            len <= WIFIRX_MAX_PSDU && n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym &&
+                            (uint32_t)(n_sym * n_dbps) <= n_steps_cap;
+            n_data[h] = ok ? n_sym * n_dbps : 0;                // multiple of 12; 0: nothing to decode
+            n_max = n_data[h] > n_max ? n_data[h] : n_max;
+        }
 #pragma unroll
         for (int k = 1; k < 64; k <<= 1) {
             int o = __shfl_xor(n_max, k, 64);
             n_max = o > n_max ? o : n_max;
         }
         if (n_max == 0) continue;
-        const uint64_t valid_mask = __ballot(valid);
+        const uint64_t valid_mask[2] = { __ballot(n_data[0] > 0), __ballot(n_data[1] > 0) };
 
-        // ---- add-compare-select ----
-        int pm[64];
-#pragma unroll
-        for (int s = 0; s < 64; s++) pm[s] = (s == 0) ? 0 : (1 << 24);
-        int best = 0;                                   // final state, taken when my frame ends
-        const int seg_steps = WR_DEC_CHUNK * WR_DEC_SEG_CHUNKS;
-        for (int seg0 = 0; seg0 < n_max; seg0 += seg_steps) {
-            // gather the received coded bits of this segment: one frame at a time, lane <-> step
-            __builtin_amdgcn_wave_barrier();
-            for (int f = 0; f < 64; f++) {
-                if (!((valid_mask >> f) & 1)) continue;
-                const int f_enc = __builtin_amdgcn_readlane(enc, f);
-                const int f_ndata = __builtin_amdgcn_readlane(n_data, f);
-                if (seg0 >= f_ndata) continue;
-                const uint8_t* fidx = idx_all + (size_t)(base + f) * max_sym * 48;
-                for (int c = 0; c < WR_DEC_SEG_CHUNKS; c++) {
-                    const int t0 = seg0 + c * WR_DEC_CHUNK;
-                    if (t0 >= f_ndata) break;
-                    const int t = t0 + lane;
-                    const bool in_range = lane < WR_DEC_CHUNK && t < f_ndata;
-                    uint64_t A1, AV, B1, BV;
-                    switch (f_enc) {
-                    case 0:  gather_chunk<0, 1>(fidx, t, in_range, A1, AV, B1, BV); break;
-                    case 1:  gather_chunk<2, 1>(fidx, t, in_range, A1, AV, B1, BV); break;
-                    case 2:  gather_chunk<0, 2>(fidx, t, in_range, A1, AV, B1, BV); break;
-                    case 3:  gather_chunk<2, 2>(fidx, t, in_range, A1, AV, B1, BV); break;
-                    case 4:  gather_chunk<0, 4>(fidx, t, in_range, A1, AV, B1, BV); break;
-                    case 5:  gather_chunk<2, 4>(fidx, t, in_range, A1, AV, B1, BV); break;
-                    case 6:  gather_chunk<1, 6>(fidx, t, in_range, A1, AV, B1, BV); break;
-                    default: gather_chunk<2, 6>(fidx, t, in_range, A1, AV, B1, BV); break;
-                    }
-                    if (lane < 4) {
-                        uint64_t wsel = lane == 0 ? A1 : lane == 1 ? AV : lane == 2 ? B1 : BV;
-                        lds[(c * 4 + lane) * 64 + f] = wsel;
-                    }
+        // ---- phase 1: gather the received coded bits of every frame, one frame at a time, lane <-> step, into the
+        //      wave's mask area [chunk][A1,AV,B1,BV][frame] (global scratch; nothing else is live in registers here) ----
+        for (int f = 0; f < WR_DECODE_FRAMES_PER_WAVE; f++) {
+            const int fh = f >> 6, fl = f & 63;
+            if (!((valid_mask[fh] >> fl) & 1)) continue;
+            const int f_enc = __builtin_amdgcn_readlane(fh ? enc[1] : enc[0], fl);
+            const int f_ndata = __builtin_amdgcn_readlane(fh ? n_data[1] : n_data[0], fl);
+            const uint8_t* fidx = idx_all + (size_t)(base + f) * max_sym * 48;
+            for (int c = 0; c * WR_DEC_CHUNK < f_ndata; c++) {
+                const int t = c * WR_DEC_CHUNK + lane;
+                const bool in_range = lane < WR_DEC_CHUNK && t < f_ndata;
+                uint64_t A1, AV, B1, BV;
+                switch (f_enc) {
+                case 0:  gather_chunk<0, 1>(fidx, t, in_range, A1, AV, B1, BV); break;
+                case 1:  gather_chunk<2, 1>(fidx, t, in_range, A1, AV, B1, BV); break;
+                case 2:  gather_chunk<0, 2>(fidx, t, in_range, A1, AV, B1, BV); break;
+                case 3:  gather_chunk<2, 2>(fidx, t, in_range, A1, AV, B1, BV); break;
+                case 4:  gather_chunk<0, 4>(fidx, t, in_range, A1, AV, B1, BV); break;
+                case 5:  gather_chunk<2, 4>(fidx, t, in_range, A1, AV, B1, BV); break;
+                case 6:  gather_chunk<1, 6>(fidx, t, in_range, A1, AV, B1, BV); break;
+                default: gather_chunk<2, 6>(fidx, t, in_range, A1, AV, B1, BV); break;
+                }
+                if (lane < 4) {
+                    uint64_t wsel = lane == 0 ? A1 : lane == 1 ? AV : lane == 2 ? B1 : BV;
+                    masks[((size_t)c * 4 + lane) * WR_DECODE_FRAMES_PER_WAVE + f] = wsel;
                 }
             }
+        }
+        __threadfence_block();
+
+        // ---- phase 2: add-compare-select ----
+        uint32_t pm[64];
+#pragma unroll
+        for (int s = 0; s < 64; s++) pm[s] = (s == 0) ? 0u : 0x10001000u;
+        int best[2] = { 0, 0 };                         // final states, taken when the frames end
+        for (int t0 = 0, c = 0; t0 < n_max; t0 += WR_DEC_CHUNK, c++) {
+            // my two frames' mask words of this chunk: global -> LDS (lane-private slots), re-read six steps at a time
             __builtin_amdgcn_wave_barrier();
-            // my frame's steps of this segment, six at a time
-            for (int c = 0; c < WR_DEC_SEG_CHUNKS; c++) {
-                const int t0 = seg0 + c * WR_DEC_CHUNK;
-                if (t0 >= n_max) break;
-                const uint64_t A1 = lds[(c * 4 + 0) * 64 + lane], AV = lds[(c * 4 + 1) * 64 + lane];
-                const uint64_t B1 = lds[(c * 4 + 2) * 64 + lane], BV = lds[(c * 4 + 3) * 64 + lane];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                lds[w * WR_DECODE_FRAMES_PER_WAVE + lane] = masks[((size_t)c * 4 + w) * WR_DECODE_FRAMES_PER_WAVE + lane];
+                lds[w * WR_DECODE_FRAMES_PER_WAVE + 64 + lane] = masks[((size_t)c * 4 + w) * WR_DECODE_FRAMES_PER_WAVE + 64 + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((c & 1) == 0 && c > 0) {
+                // every 120 steps: subtract the common minimum of each frame (register phase 0 here; decisions see
+                // differences only)
+                uint32_t mn = pm[0];
+#pragma unroll
+                for (int s = 1; s < 64; s++) mn = pk_min(mn, pm[s]);
+#pragma unroll
+                for (int s = 0; s < 64; s++) pm[s] = pk_sub(pm[s], mn);
+            }
+            {
                 for (int g = 0; g < WR_DEC_CHUNK / 6; g++) {
                     const int tg = t0 + 6 * g;
                     if (tg >= n_max) break;
-                    const uint32_t a1 = (uint32_t)(A1 >> (6 * g)), av = (uint32_t)(AV >> (6 * g));
-                    const uint32_t b1 = (uint32_t)(B1 >> (6 * g)), bv = (uint32_t)(BV >> (6 * g));
-                    const bool mine = tg < n_data;
-                    if (mine) {
+                    // six steps of the four mask words, frame A in bits 0..5, frame B in bits 16..21 (re-read from LDS
+                    // every group: registers are what this kernel is short of)
+                    uint32_t pw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const uint64_t wa = lds[w * WR_DECODE_FRAMES_PER_WAVE + lane];
+                        const uint64_t wb = lds[w * WR_DECODE_FRAMES_PER_WAVE + 64 + lane];
+                        pw[w] = ((uint32_t)(wa >> (6 * g)) & 0x3fu) | (((uint32_t)(wb >> (6 * g)) & 0x3fu) << 16);
+                    }
+                    const bool mine0 = tg < n_data[0], mine1 = tg < n_data[1];
+                    if (mine0 || mine1) {
 #define WR_ACS(P)                                                                                         \
                         {                                                                                 \
-                            const int va = (av >> P) & 1, vb = (bv >> P) & 1;                             \
-                            const int ta = (a1 >> P) & 1 & va, tb = (b1 >> P) & 1 & vb, nv = va + vb;     \
-                            int M[2][2];                                                                  \
+                            const uint32_t ta = (pw[0] >> P) & k1, va = (pw[1] >> P) & k1;                \
+                            const uint32_t tb = (pw[2] >> P) & k1, vb = (pw[3] >> P) & k1;                \
+                            const uint32_t nv = va + vb;          /* a set bit implies its valid bit */   \
+                            uint32_t M[2][2];                                                             \
                             M[0][0] = ta + tb;                                                            \
                             M[0][1] = ta + vb - tb;                                                       \
                             M[1][1] = nv - M[0][0];                                                       \
                             M[1][0] = nv - M[0][1];                                                       \
-                            uint32_t dlo = 0, dhi = 0;                                                    \
-                            acs_step<P>(pm, M, dlo, dhi);                                                 \
-                            surv[(size_t)(tg + P) * 64 + lane] = ((uint64_t)dhi << 32) | dlo;             \
+                            uint32_t acc[4];                                                              \
+                            acs_step<P>(pm, M, acc, k15, k2);                                             \
+                            *reinterpret_cast<uint4*>(surv + ((size_t)(tg + P) * 64 + lane) * 4) =        \
+                                make_uint4(acc[0], acc[1], acc[2], acc[3]);                               \
                         }
                         WR_ACS(0) WR_ACS(1) WR_ACS(2) WR_ACS(3) WR_ACS(4) WR_ACS(5)
 #undef WR_ACS
                     }
-                    if (__any(mine && tg + 6 == n_data)) {
-                        // my frame just ended (register phase 0 again): smallest metric, lowest state
-                        int bm = pm[0], bs = 0;
+                    const bool end0 = mine0 && tg + 6 == n_data[0], end1 = mine1 && tg + 6 == n_data[1];
+                    if (__any(end0 || end1)) {
+                        // a frame just ended (register phase 0 again): smallest metric, lowest state
+                        uint32_t bm0 = pm[0] & 0xffffu, bm1 = pm[0] >> 16;
+                        int bs0 = 0, bs1 = 0;
 #pragma unroll
                         for (int s = 1; s < 64; s++) {
-                            if (pm[s] < bm) { bm = pm[s]; bs = s; }
+                            const uint32_t v0 = pm[s] & 0xffffu, v1 = pm[s] >> 16;
+                            if (v0 < bm0) { bm0 = v0; bs0 = s; }
+                            if (v1 < bm1) { bm1 = v1; bs1 = s; }
                         }
-                        if (mine && tg + 6 == n_data) best = bs;
+                        if (end0) best[0] = bs0;
+                        if (end1) best[1] = bs1;
                     }
                 }
             }
         }
         __threadfence_block();
-        // ---- traceback: 32 decoded bits per word, words stored [word][lane] ----
+        // ---- traceback of both frames: 32 decoded bits per word, words stored [word][A/B][lane].  The survivor
+        //      row of a step does not depend on the path (only the piece picked from it does), so eight rows are
+        //      loaded ahead of the eight dependent state updates: one memory round trip per eight steps ----
         {
-            int st = best;
-            uint32_t word = 0;
-            for (int t = n_max - 1; t >= 0; t--) {
-                const bool mine = t < n_data;
-                uint64_t sv = 0;
-                if (mine) sv = surv[(size_t)t * 64 + lane];
-                const uint32_t half = (st < 32) ? (uint32_t)sv : (uint32_t)(sv >> 32);
-                const uint32_t h = (half >> (31 - (st & 31))) & 1u;
-                if (mine) {
-                    word |= (uint32_t)(st & 1) << (t & 31);
-                    st = (st >> 1) | (int)(h << 5);
-                    if ((t & 31) == 0) {
-                        dbits[(size_t)(t >> 5) * 64 + lane] = word;
-                        word = 0;
-                    }
-                }
-            }
-        }
-        __threadfence_block();
-        // ---- descramble (x^7+x^4+1, state from the first 7 decoded bits), bytes, CRC-32 ----
-        if (valid) {
-            uint32_t w0 = dbits[lane];
-            int state = 0;
-#pragma unroll
-            for (int i = 0; i < 7; i++) state |= (int)((w0 >> i) & 1) << (6 - i);
-            // positions 7..15 belong to the SERVICE field: advance the scrambler
-            for (int i = 7; i < 16; i++) {
-                int fb = ((state >> 6) ^ (state >> 3)) & 1;
-                state = ((state << 1) & 0x7e) | fb;
-            }
-            uint8_t* psdu = psdu_all + (size_t)slot * psdu_stride;
-            uint32_t crc = 0xffffffffu;
-            uint32_t cur = w0;
-            int wi = 0;
-            for (int b = 0; b < psdu_len; b++) {
-                uint32_t byte = 0;
+            int st0 = best[0], st1 = best[1];
+            uint32_t word0 = 0, word1 = 0;
+            for (int t1 = n_max - 1; t1 >= 0; t1 -= 8) {
+                uint4 rows[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    const int i = 16 + 8 * b + k;
-                    if ((i >> 5) != wi) { wi = i >> 5; cur = dbits[(size_t)wi * 64 + lane]; }
-                    const uint32_t fb = (uint32_t)(((state >> 6) ^ (state >> 3)) & 1);
-                    state = ((state << 1) & 0x7e) | (int)fb;
-                    const uint32_t d = ((cur >> (i & 31)) & 1u) ^ fb;
-                    byte |= d << k;
-                    crc = crc32_bit(crc, d);
+                    const int t = t1 - k;
+                    rows[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (t >= 0 && (t < n_data[0] || t < n_data[1]))
+                        rows[k] = *reinterpret_cast<const uint4*>(surv + ((size_t)t * 64 + lane) * 4);
                 }
-                psdu[b] = (uint8_t)byte;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int t = t1 - k;
+                    const bool mine0 = t >= 0 && t < n_data[0], mine1 = t >= 0 && t < n_data[1];
+                    const int i0 = st0 >> 4, i1 = st1 >> 4;
+                    const uint32_t p0 = i0 == 0 ? rows[k].x : i0 == 1 ? rows[k].y : i0 == 2 ? rows[k].z : rows[k].w;
+                    const uint32_t p1 = i1 == 0 ? rows[k].x : i1 == 1 ? rows[k].y : i1 == 2 ? rows[k].z : rows[k].w;
+                    const uint32_t h0 = (p0 >> (15 - (st0 & 15))) & 1u, h1 = (p1 >> (31 - (st1 & 15))) & 1u;
+                    if (mine0) {
+                        word0 |= (uint32_t)(st0 & 1) << (t & 31);
+                        st0 = (st0 >> 1) | (int)(h0 << 5);
+                        if ((t & 31) == 0) { dbits[(size_t)(t >> 5) * 128 + lane] = word0; word0 = 0; }
+                    }
+                    if (mine1) {
+                        word1 |= (uint32_t)(st1 & 1) << (t & 31);
+                        st1 = (st1 >> 1) | (int)(h1 << 5);
+                        if ((t & 31) == 0) { dbits[(size_t)(t >> 5) * 128 + 64 + lane] = word1; word1 = 0; }
+                    }
+                }
             }
-            crc = ~crc;
-            uint32_t fl = fr.flags | WIFIRX_F_DECODED;
-            if (psdu_len >= 4 && crc == 558161692u) fl |= WIFIRX_F_CRC_OK; else fl &= ~WIFIRX_F_CRC_OK;
-            frames[slot].flags = fl;
+        }
+        __threadfence_block();
+        // ---- descramble, bytes, CRC-32 ----
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (n_data[h] > 0) {                               // the record is re-read: nothing of it was kept in registers
+                const uint32_t slot = base + 64 * h + lane;
+                finish_frame(dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
+                             frames + slot, frames[slot].flags);
+            }
         }
     }
 }

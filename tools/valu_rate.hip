@@ -27,6 +27,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters)
             asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
         } else if (KIND == 7) {
             asm volatile("v_cmp_lt_i32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n v_cmp_lt_i32 vcc, %1, %3\n v_cndmask_b32 %1, %1, %3, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "vcc");
+        } else if (KIND == 9) {
+            asm volatile("v_pk_sub_i16 %0, %0, %4\n v_pk_lshrrev_b16 %1, 15, %1\n v_pk_mad_u16 %2, %2, %4, %1\n v_pk_sub_i16 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
         } else {
             asm volatile("v_pk_fma_f16 %0, %0, %4, %4\n v_pk_fma_f16 %1, %1, %4, %4\n v_pk_fma_f16 %2, %2, %4, %4\n v_pk_fma_f16 %3, %3, %4, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
         }
@@ -49,6 +51,6 @@ int main()
 {
     for (int w : {1, 2, 4, 8}) { run<0>("v_fma_f32", 8, w); }
     for (int w : {1, 4}) { run<1>("v_pk_fma_f32", 4, w); run<2>("v_fma_f64", 4, w); run<3>("v_rcp_f32", 4, w); }
-    for (int w : {4, 8}) { run<4>("v_pk_add_u16", 4, w); run<5>("v_pk_min_u16", 4, w); run<6>("v_add_u32", 4, w); run<7>("cmp+cndmask+addc", 6, w); run<8>("v_pk_fma_f16", 4, w); }
+    for (int w : {4, 8}) { run<4>("v_pk_add_u16", 4, w); run<5>("v_pk_min_u16", 4, w); run<6>("v_add_u32", 4, w); run<7>("cmp+cndmask+addc", 6, w); run<8>("v_pk_fma_f16", 4, w); run<9>("pk sub/lshr/mad", 4, w); }
     return 0;
 }
