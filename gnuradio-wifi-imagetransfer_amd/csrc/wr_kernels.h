@@ -9,7 +9,6 @@
 #ifndef WR_DEMOD_WAVES_PER_SIMD
 #define WR_DEMOD_WAVES_PER_SIMD 4       // register budget of the demod kernels: 512/4 = 128 VGPRs
 #endif
-#define WR_YLDS_FLOATS     768      // 384 complex: the 383 coarse-derotated samples sync_long correlates
 #define WR_STREAM_SPAN     16       // tiles of 64 samples one wave scans in stream-mode detection
 #define WR_DECODE_MAX_WAVES 4096    // waves of the decode kernel (grid-stride; each owns a scratch slice)
 #define WR_DECODE_FRAMES_PER_WAVE 128   // two frames per lane: packed 16-bit path metrics

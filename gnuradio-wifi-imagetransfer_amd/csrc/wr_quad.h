@@ -20,16 +20,6 @@
 
 namespace wr {
 
-// Keeps the instruction scheduler from interleaving the four independent per-sample chains of a lane:
-// interleaved they need ~190 VGPRs (2 waves/SIMD); one after the other the kernel fits 4-5 waves/SIMD,
-// and waves, not chains, hide the latencies.
-#ifndef WR_PREFETCH
-#define WR_PREFETCH 0      // 1: load the next symbol's samples one iteration ahead (+8 VGPRs)
-#endif
-#ifndef WR_SCHED_FENCE
-#define WR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-
 #define WR_QLDS_SCRATCH 768
 #define WR_QLDS_H       (WR_QLDS_SCRATCH)            // 4 x 64 float2: channel estimate, lane-private slots
 #define WR_QLDS_TW      (WR_QLDS_H + 512)              // 6 x 16 float2: stage-1/2 twiddles by row lane
@@ -431,13 +421,6 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     float*   llr = (llr_all && out >= 0) ? llr_all + (size_t)out * per * prm.llr_bits : nullptr;
     float2*  car = (car_all && out >= 0) ? car_all + (size_t)out * per : nullptr;
 
-    // samples of symbol 0, then always one symbol ahead of the arithmetic (hides the HBM latency that
-    // 2-4 waves per SIMD cannot); loads are bounds-checked only, a symbol that turns out not to exist
-    // is simply not used
-    c32 nx[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) nx[j] = WR_PREFETCH ? load_y(xb, fs + r + 16 * j, m_lo, m_hi) : c32{ 0.0f, 0.0f };
-
     for (int s = 0;; s++) {
         const int off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
         bool act = alive && (s <= n_sym + 2);
@@ -451,15 +434,6 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         // ---- samples r + 16 j of the symbol (rows without a symbol get zeros) ----
         c32 v[4], cur[4];
         {
-            const int offn = fs + (s + 1 < 2 ? 64 * (s + 1) : 128 + 80 * (s - 1) + 16);
-#if WR_PREFETCH
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                cur[j] = nx[j];
-                nx[j] = load_y(xb, offn + r + 16 * j, m_lo, m_hi);
-            }
-#else
-            (void)offn;
             if (lo_zero) {              // act => off0 + 63 < L <= m_hi: every sample of the symbol is in range
                 float2 t[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
                 if (act) {
@@ -473,7 +447,6 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #pragma unroll
                 for (int j = 0; j < 4; j++) cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
             }
-#endif
         }
         {   // one rotation by the total offset: base phasor from a double angle, then steps of exp(j theta 16)
             c32 w;
@@ -481,12 +454,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             ph += (s == 0) ? (q80 - Qp * 16ull) : q80;          // next symbol starts 64 (s = 0) or 80 samples later
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-#if WR_PREFETCH
-                c32 xs = act ? cur[j] : c32{ 0.0f, 0.0f };       // prefetched regardless of act
-#else
-                c32 xs = cur[j];                                   // rows without a symbol loaded zeros above
-#endif
-                v[j] = sp_cmul(xs, w);
+                v[j] = sp_cmul(cur[j], w);                         // rows without a symbol loaded zeros above
                 w = sp_cmul(w, u16);
             }
         }
