@@ -119,8 +119,8 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
     if (cfg->max_sym == 0 || cfg->max_sym > WIFIRX_MAX_SYM) return fail(nullptr, WIFIRX_EINVAL, "max_sym out of range");
     if (!(cfg->llr_bits == 0 || cfg->llr_bits == 1 || cfg->llr_bits == 2 || cfg->llr_bits == 4 || cfg->llr_bits == 6))
         return fail(nullptr, WIFIRX_EINVAL, "llr_bits must be 0,1,2,4,6");
-    if (cfg->chan_est != WIFIRX_EQ_LS && cfg->chan_est != WIFIRX_EQ_LMS)
-        return fail(nullptr, WIFIRX_EINVAL, "only the LS and LMS equalizers are implemented");
+    if (cfg->chan_est < WIFIRX_EQ_LS || cfg->chan_est > WIFIRX_EQ_STA)
+        return fail(nullptr, WIFIRX_EINVAL, "chan_est must be one of WIFIRX_EQ_LS, LMS, COMB, STA");
     if (!(cfg->bandwidth > 0) || !(cfg->frequency > 0)) return fail(nullptr, WIFIRX_EINVAL, "bandwidth/frequency must be > 0");
     if (cfg->min_plateau < 0 || cfg->min_plateau > 32) return fail(nullptr, WIFIRX_EINVAL, "min_plateau out of range");
     int ndev = 0;
@@ -173,8 +173,8 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
         h->cfg.sensitivity = (float)value;
         return WIFIRX_OK;
     case WIFIRX_P_CHAN_EST:
-        if ((int)value != WIFIRX_EQ_LS && (int)value != WIFIRX_EQ_LMS)
-            return fail(h, WIFIRX_EINVAL, "only the LS and LMS equalizers are implemented");
+        if ((int)value < WIFIRX_EQ_LS || (int)value > WIFIRX_EQ_STA)
+            return fail(h, WIFIRX_EINVAL, "chan_est must be one of WIFIRX_EQ_LS, LMS, COMB, STA");
         h->cfg.chan_est = (int)value;
         return WIFIRX_OK;
     default:

@@ -129,13 +129,13 @@ __device__ __forceinline__ uint32_t sync_after_trigger(const float2* x, long n_s
     return ok ? (WIFIRX_F_DETECTED | WIFIRX_F_SYNC) : WIFIRX_F_DETECTED;
 }
 
-template <bool LMS>
-__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, LMS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
+template <int EQ>
+__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ != WIFIRX_EQ_LS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
                         DemodParams prm, wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
                         float* __restrict__ llr, float2* __restrict__ carrier, float2* __restrict__ csi)
 {
-    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS];
+    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t slot0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;
@@ -166,7 +166,7 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
     if ((lane & 15) == 0 && seed.out >= 0) { frames[seed.out].flags = seed.flags; frames[seed.out].frame_start = seed.fs; frames[seed.out].cfo_fine = seed.cfo_f; frames[seed.out].trigger = (int)seed.t; }
     return;
 #endif
-    frames_quad<LMS>(seed, prm, lds[wave], lane, frames, idx, llr, carrier, csi);
+    frames_quad<EQ>(seed, prm, lds[wave], lane, frames, idx, llr, carrier, csi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -195,14 +195,14 @@ void stream_detect_kernel(const float2* __restrict__ x, long n_samp, long tile0,
 }
 
 // one wave per four selected triggers of the stream
-template <bool LMS>
-__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, LMS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
+template <int EQ>
+__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ != WIFIRX_EQ_LS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
 void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const StreamTrig* __restrict__ trig,
                          uint32_t n_trig, DemodParams prm, const float2* __restrict__ A,
                          wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
                          float* __restrict__ llr, float2* __restrict__ carrier, float2* __restrict__ csi)
 {
-    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS];
+    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t k0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;
@@ -225,7 +225,7 @@ void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const Stream
             seed.fs = fs; seed.flags = flags; seed.out = k;
         }
     }
-    frames_quad<LMS>(seed, prm, lds[wave], lane, frames, idx, llr, carrier, csi);
+    frames_quad<EQ>(seed, prm, lds[wave], lane, frames, idx, llr, carrier, csi);
 }
 
 }  // namespace wr
@@ -236,10 +236,12 @@ extern "C" hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, ui
 {
     if (n_slots == 0) return hipSuccess;
     dim3 grid((n_slots + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
-    if (prm->chan_est == WIFIRX_EQ_LMS)
-        hipLaunchKernelGGL(wr::demod_batch_kernel<true>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi);
-    else
-        hipLaunchKernelGGL(wr::demod_batch_kernel<false>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi);
+    switch (prm->chan_est) {
+    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi); break;
+    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi); break;
+    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi); break;
+    default:             hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi); break;
+    }
     return hipGetLastError();
 }
 
@@ -259,9 +261,11 @@ extern "C" hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, in
 {
     if (n_trig == 0) return hipSuccess;
     dim3 grid((n_trig + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
-    if (prm->chan_est == WIFIRX_EQ_LMS)
-        hipLaunchKernelGGL(wr::demod_stream_kernel<true>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi);
-    else
-        hipLaunchKernelGGL(wr::demod_stream_kernel<false>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi);
+    switch (prm->chan_est) {
+    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi); break;
+    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi); break;
+    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi); break;
+    default:             hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi); break;
+    }
     return hipGetLastError();
 }

@@ -25,6 +25,8 @@ namespace wr {
 #define WR_QLDS_TW      (WR_QLDS_H + 512)              // 6 x 16 float2: stage-1/2 twiddles by row lane
 #define WR_QLDS_PREV    (WR_QLDS_TW + 192)             // 4 rows x 4 float2: pilots of the previous symbol
 #define WR_QLDS_FLOATS  (WR_QLDS_PREV + 32)          // per wave: max(383 preamble samples, 4 rows x 64 values) complex
+#define WR_QLDS_DH      (WR_QLDS_FLOATS)             // COMB only: 4 x 64 float2, the running estimate d_H
+#define WR_QLDS_FLOATS_EQ(EQ) (WR_QLDS_FLOATS + ((EQ) == WIFIRX_EQ_COMB ? 512 : 0))
 
 __device__ __forceinline__ c32 load_sample(const float2* __restrict__ x, long n, long n_samp)
 {
@@ -338,14 +340,18 @@ __device__ __forceinline__ c32 point_of(unsigned idx, int n_bpsc)
     return p;
 }
 
-// LMS = false: LS equaliser (channel estimate from the LTS, held for the frame; multiplier form).
-// LMS = true:  decision-directed LMS (ieee802_11.LMS): Y = X/H, then H = H/2 + (X/point)/2 on every data bin.
-template <bool LMS>
+// EQ = WIFIRX_EQ_LS:   channel estimate from the LTS, held for the frame; multiplier form.
+// EQ = WIFIRX_EQ_LMS:  decision-directed (ieee802_11.LMS): Y = X/H, then H = H/2 + (X/point)/2 on every data bin.
+// EQ = WIFIRX_EQ_COMB: the four pilots of every symbol, interpolated over the band, smoothed over time.
+// EQ = WIFIRX_EQ_STA:  spectral-temporal averaging of the per-bin estimates X/point.
+template <int EQ>
 __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodParams& prm, float* qlds, int lane,
                                             wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx_all,
                                             float* __restrict__ llr_all, float2* __restrict__ car_all,
                                             float2* __restrict__ csi_all)
 {
+    constexpr bool LMS = EQ == WIFIRX_EQ_LMS, COMB = EQ == WIFIRX_EQ_COMB, STA = EQ == WIFIRX_EQ_STA;
+    constexpr bool DIV = EQ != WIFIRX_EQ_LS;         // Y = X / H by division (LS multiplies by G = conj(H)/|H|^2)
     const int row = lane >> 4, r = lane & 15;
     // ---- row-uniform frame state, one copy per lane ----
     // Samples are addressed as xb[m], m = index into the copied stream y (xb = x + trigger - 16); m is valid
@@ -400,6 +406,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     }
     float2* Hl = reinterpret_cast<float2*>(qlds + WR_QLDS_H) + lane;      // element j at Hl[64 j]
     float2* pvl = reinterpret_cast<float2*>(qlds + WR_QLDS_PREV) + 4 * row;
+    float2* DHl = reinterpret_cast<float2*>(qlds + (COMB ? WR_QLDS_DH : WR_QLDS_H)) + lane;   // COMB: d_H; else = Hl
+    float cw[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, cu[4] = { 0.0f, 0.0f, 0.0f, 0.0f };           // COMB: interpolation weights
+    if (COMB) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cw[j] = WR_COMB_W[r + 16 * j]; cu[j] = WR_COMB_U[r + 16 * j]; }
+    }
     int carrier0[4];                     // data carrier number 0..47 of bin r + 16 j, -1 for pilots / DC / guards
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -556,6 +568,28 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             double alpha = 0.1;
             d_er = (1 - alpha) * d_er + alpha * er;
         }
+        // (6a) COMB: this symbol's pilots (polarity removed) are the channel at bins 11, 25, 39, 53, their mean stands at
+        //      the band edges (bins 0 and 64); linear interpolation, then d_H = 0.8 d_H + 0.2 H (d_H = H at s = 0)
+        if (COMB) {
+            c32 n1 = row_bcast<11>(X[0]), n2 = row_bcast<9>(X[1]), n3 = row_bcast<7>(X[2]), n4 = row_bcast<5>(X[3]);
+            if (s < 2) n2 = cneg(n2);
+            else { n1 = cflip(n1, sgn); n2 = cflip(n2, sgn); n3 = cflip(n3, sgn); n4 = cflip(n4, sgn ^ 0x80000000u); }
+            const c32 sum = cadd(cadd(cadd(n1, n2), n3), n4);
+            const c32 n0 = { 0.25f * sum.re, 0.25f * sum.im };
+            const c32 node[6] = { n0, n1, n2, n3, n4, n0 };
+            const int edge[4] = { 11, 25, 39, 53 };
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool lo = (r + 16 * j) <= edge[j];            // segment j (nodes j, j+1) or j+1 (nodes j+1, j+2)
+                const c32 a = lo ? node[j] : node[j + 1], b = lo ? node[j + 1] : node[j + 2];
+                const float hr = fma_(b.re, cw[j], a.re * cu[j]), hi = fma_(b.im, cw[j], a.im * cu[j]);
+                if (s == 0) DHl[64 * j] = make_float2(hr, hi);
+                else {
+                    const float2 o = DHl[64 * j];
+                    DHl[64 * j] = make_float2(0.8f * o.x + 0.2f * hr, 0.8f * o.y + 0.2f * hi);
+                }
+            }
+        }
         // (6) LS equalizer
         if (s == 0) {
 #pragma unroll
@@ -574,8 +608,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 float g = 0.5f * WR_LTS_FREQ[i];
                 const float hr = u.re * g, hi = u.im * g;
                 if (csi_all && usedj && act) csi_all[(size_t)out * 52 + (i - 6 - (i > 32))] = make_float2(hr, hi);
-                if (LMS) {
+                if (LMS || STA) {
                     Hl[64 * j] = usedj ? make_float2(hr, hi) : make_float2(1.0f, 0.0f);
+                } else if (COMB) {
+                    // COMB equalises with d_H (own LDS area); the LS estimate only feeds the SNR figure and the CSI
                 } else {
                     // G = conj(H)/|H|^2 replaces H in LDS: the one-tap equaliser as a multiplier
                     const float dd = fma_(hi, hi, hr * hr);
@@ -592,28 +628,65 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         } else {
             c32 Y[4];
             int carrier[4];
+            c32 HU[4];                                   // STA: this symbol's per-bin estimates of my bins
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 carrier[j] = carrier0[j];
                 asm volatile("" : "+v"(carrier[j]));     // keeps base + carrier out of loop-invariant registers
                 Y[j] = { 0.0f, 0.0f };
+                HU[j] = X[j];
                 // LS: every bin is multiplied (G = 0 on unused bins; pilot bins are never stored)
-                if (!LMS || carrier[j] >= 0) {
-                    const float2 g0 = Hl[64 * j];
-                    if (LMS) {
+                if (!DIV || carrier[j] >= 0) {
+                    const float2 g0 = DHl[64 * j];
+                    if (DIV) {
                         const float d = fma_(g0.y, g0.y, g0.x * g0.x);
                         Y[j].re = fma_(X[j].im, g0.y, X[j].re * g0.x) / d;
                         Y[j].im = fma_(X[j].im, g0.x, -(X[j].re * g0.y)) / d;
-                        const int nbl = (s == 2) ? 1 : n_bpsc;
-                        const c32 pt = point_of(decide(Y[j], nbl), nbl);
-                        const float dp = fma_(pt.im, pt.im, pt.re * pt.re);
-                        const float tr = fma_(X[j].im, pt.im, X[j].re * pt.re) / dp;
-                        const float ti = fma_(X[j].im, pt.re, -(X[j].re * pt.im)) / dp;
-                        if (act) Hl[64 * j] = make_float2(0.5f * g0.x + 0.5f * tr, 0.5f * g0.y + 0.5f * ti);
+                        if (LMS || STA) {
+                            const int nbl = (s == 2) ? 1 : n_bpsc;
+                            const c32 pt = point_of(decide(Y[j], nbl), nbl);
+                            const float dp = fma_(pt.im, pt.im, pt.re * pt.re);
+                            const float tr = fma_(X[j].im, pt.im, X[j].re * pt.re) / dp;
+                            const float ti = fma_(X[j].im, pt.re, -(X[j].re * pt.im)) / dp;
+                            if (LMS && act) Hl[64 * j] = make_float2(0.5f * g0.x + 0.5f * tr, 0.5f * g0.y + 0.5f * ti);
+                            HU[j] = { tr, ti };
+                        }
                     } else {
                         Y[j] = sp_cmul(X[j], c32{ g0.x, g0.y });
                     }
                 }
+            }
+            if (STA) {
+                // pilots: X times the known pilot value; then every used bin takes the mean of the estimates of the used
+                // bins within +-2 (ascending), and H = H/2 + mean/2.  The exchange goes through the FFT's LDS area.
+                if (r == 11) HU[0] = cflip(X[0], sgn);
+                if (r == 9)  HU[1] = cflip(X[1], sgn);
+                if (r == 7)  HU[2] = cflip(X[2], sgn);
+                if (r == 5)  HU[3] = cflip(X[3], sgn ^ 0x80000000u);
+                float2* hu = reinterpret_cast<float2*>(qlds) + 64 * row;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; j++) hu[r + 16 * j] = make_float2(HU[j].re, HU[j].im);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int i = r + 16 * j;
+                    const bool usedj = (i >= 6 && i <= 58 && i != 32);
+                    c32 sum = { 0.0f, 0.0f };
+                    int cnt = 0;
+#pragma unroll
+                    for (int dk = -2; dk <= 2; dk++) {
+                        const int k = i + dk;
+                        const bool ok = (k >= 6 && k <= 58 && k != 32);
+                        const float2 v = hu[ok ? k : i];
+                        const c32 add = (cnt > 0) ? cadd(sum, c32{ v.x, v.y }) : c32{ v.x, v.y };
+                        if (ok) { sum = add; cnt++; }
+                    }
+                    const float fc_ = (float)(cnt > 0 ? cnt : 1);
+                    const float2 o = Hl[64 * j];
+                    if (act && usedj) Hl[64 * j] = make_float2(0.5f * o.x + 0.5f * (sum.re / fc_), 0.5f * o.y + 0.5f * (sum.im / fc_));
+                }
+                __builtin_amdgcn_wave_barrier();
             }
             if (s == 2) {
                 // (7) SIGNAL: per frame, gather the 48 BPSK decisions in carrier order, de-interleave, Viterbi

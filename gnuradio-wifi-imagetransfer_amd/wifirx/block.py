@@ -67,7 +67,7 @@ class wifi_phy_rx(grshim.sync_block):
         return self.chan_est
 
     def set_chan_est(self, chan_est):
-        self._rx.set_param(capi.P_CHAN_EST, int(chan_est))     # LS and LMS; raises WifiRxError for COMB/STA
+        self._rx.set_param(capi.P_CHAN_EST, int(chan_est))     # LS, LMS, COMB, STA
         self.chan_est = int(chan_est)
 
     set_algorithm = set_chan_est                                # frame_equalizer.set_algorithm

@@ -96,7 +96,7 @@ typedef struct wifirx_config {
     double   frequency;    /* carrier in Hz:    wifi_phy_hier `frequency` (grc:501-510) */
     float    sensitivity;  /* sync_short threshold: wifi_phy_hier `sensitivity` (grc:681-690), 0.56 */
     int32_t  min_plateau;  /* sync_short min_plateau, 2 (gnu_radio/IRS_AP.py:268) */
-    int32_t  chan_est;     /* WIFIRX_EQ_*: wifi_phy_hier `chan_est` (grc:299-308); LS and LMS implemented */
+    int32_t  chan_est;     /* WIFIRX_EQ_*: wifi_phy_hier `chan_est` (grc:299-308, IRS_AP.py:139-141) */
     uint32_t max_sym;      /* output capacity per frame in data symbols (<= WIFIRX_MAX_SYM) */
     uint32_t llr_bits;     /* LLR capacity per sub-carrier (0 = no LLR output, else 1,2,4,6) */
     uint32_t want_carrier; /* 1: also write the 48 equalised points per symbol (`carrier` port) */

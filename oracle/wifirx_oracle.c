@@ -50,7 +50,7 @@ typedef struct orc_params {
     int32_t math_mode;
     int32_t max_sym;      /* output capacity per frame (data symbols) */
     int32_t llr_bits;     /* 0: no llr */
-    int32_t chan_est;     /* WIFIRX_EQ_LS or WIFIRX_EQ_LMS */
+    int32_t chan_est;     /* WIFIRX_EQ_LS / LMS / COMB / STA */
 } orc_params;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -674,9 +674,10 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     c32 u16;                                                    /* exp(j theta 16) */
     sp_sincos_q(Qp * 16u, &u16.im, &u16.re);
     c32 prev[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
-    c32 H[64], G[64];
+    c32 H[64], G[64], DH[64];                                   /* DH: running estimate of COMB / STA */
     memset(H, 0, sizeof H);
     memset(G, 0, sizeof G);
+    memset(DH, 0, sizeof DH);
     int n_sym = 0, n_bpsc = 1, enc = 0, psdu_len = 0, have_signal = 0;
     int n_out = 0;
     float snr = 0.0f;
@@ -802,7 +803,36 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             double alpha = 0.1;
             d_er = (1 - alpha) * d_er + alpha * er;
         }
-        /* (6) LS equalizer */
+                /* (6a) COMB (ieee802_11.COMB; definition: DESIGN.md section 4.11 -- upstream's source is absent, restated from
+         * the published comb-pilot scheme): the four pilots of THIS symbol, polarity removed, are the channel at bins
+         * 11, 25, 39, 53; the band edges (bins 0 and 64) take their mean; linear interpolation in between; the frame's
+         * estimate follows with d_H = 0.8 d_H + 0.2 H (d_H = H on the first long training symbol). */
+        if (prm->chan_est == WIFIRX_EQ_COMB) {
+            const float pl = (s >= 2) ? (float)WR_POLARITY[(s - 2) % 127] : 1.0f;
+            c32 node[6];
+            if (s < 2) { node[1] = X[11]; node[2] = cneg(X[25]); node[3] = X[39]; node[4] = X[53]; }
+            else {
+                node[1] = pl < 0 ? cneg(X[11]) : X[11];
+                node[2] = pl < 0 ? cneg(X[25]) : X[25];
+                node[3] = pl < 0 ? cneg(X[39]) : X[39];
+                node[4] = pl < 0 ? X[53] : cneg(X[53]);
+            }
+            c32 sum = cadd(cadd(cadd(node[1], node[2]), node[3]), node[4]);
+            node[0].re = 0.25f * sum.re; node[0].im = 0.25f * sum.im;
+            node[5] = node[0];
+            for (int i = 0; i < 64; i++) {
+                const c32 a = node[WR_COMB_SEG[i]], b = node[WR_COMB_SEG[i] + 1];
+                c32 h;
+                h.re = fmaf(b.re, WR_COMB_W[i], a.re * WR_COMB_U[i]);
+                h.im = fmaf(b.im, WR_COMB_W[i], a.im * WR_COMB_U[i]);
+                if (s == 0) DH[i] = h;
+                else {
+                    DH[i].re = 0.8f * DH[i].re + 0.2f * h.re;
+                    DH[i].im = 0.8f * DH[i].im + 0.2f * h.im;
+                }
+            }
+        }
+/* (6) LS equalizer */
         if (s == 0) {
             memcpy(H, X, sizeof H);
         } else if (s == 1) {
@@ -834,6 +864,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 }
                 snr = (float)(10 * log10(signal / noise / 2));
             }
+            if (prm->chan_est == WIFIRX_EQ_STA) memcpy(DH, H, sizeof DH);     /* STA starts from the LS estimate */
             fr->snr_db = snr;
             if (csi) {            /* channel state: the LS estimate on the 52 occupied bins, ascending */
                 int k = 0;
@@ -842,12 +873,25 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
         } else {
             uint8_t bits48[48];
             c32     sym48[48];
+            c32     HU[64];                                     /* STA: per-bin estimates of this symbol */
+            memset(HU, 0, sizeof HU);
             int     c = 0;
             int     nb = (s == 2) ? 1 : n_bpsc;
             for (int i = 0; i < 64; i++) {
                 if (i == 11 || i == 25 || i == 32 || i == 39 || i == 53 || i < 6 || i > 58) continue;
                 c32 yq;
-                if (spec && prm->chan_est == WIFIRX_EQ_LMS) {
+                if (prm->chan_est == WIFIRX_EQ_COMB || prm->chan_est == WIFIRX_EQ_STA) {
+                    /* Y = X / d_H (for STA: the estimate of the previous symbol; it is updated below) */
+                    float d = fmaf(DH[i].im, DH[i].im, DH[i].re * DH[i].re);
+                    yq.re = fmaf(X[i].im, DH[i].im, X[i].re * DH[i].re) / d;
+                    yq.im = fmaf(X[i].im, DH[i].re, -(X[i].re * DH[i].im)) / d;
+                    if (prm->chan_est == WIFIRX_EQ_STA) {
+                        c32 pt = point_of(decide(yq, nb), nb);
+                        float dp = fmaf(pt.im, pt.im, pt.re * pt.re);
+                        HU[i].re = fmaf(X[i].im, pt.im, X[i].re * pt.re) / dp;
+                        HU[i].im = fmaf(X[i].im, pt.re, -(X[i].re * pt.im)) / dp;
+                    }
+                } else if (spec && prm->chan_est == WIFIRX_EQ_LMS) {
                     /* LMS (decision directed): Y = X/H, then H = H/2 + (X/point)/2 */
                     float d = fmaf(H[i].im, H[i].im, H[i].re * H[i].re);
                     yq.re = fmaf(X[i].im, H[i].im, X[i].re * H[i].re) / d;
@@ -874,6 +918,30 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 sym48[c] = yq;
                 bits48[c] = decide(yq, nb);
                 c++;
+            }
+            if (prm->chan_est == WIFIRX_EQ_STA) {
+                /* STA (ieee802_11.STA; definition: DESIGN.md section 4.11, after Fernandez et al., spectral-temporal
+                 * averaging with alpha = 0.5, beta = 2): per-bin estimates X/point on the data bins and X * (known
+                 * pilot) on the pilots, averaged over the used bins within +-2, then d_H = d_H/2 + average/2. */
+                const float pl = (float)WR_POLARITY[(s - 2) % 127];
+                HU[11] = pl < 0 ? cneg(X[11]) : X[11];
+                HU[25] = pl < 0 ? cneg(X[25]) : X[25];
+                HU[39] = pl < 0 ? cneg(X[39]) : X[39];
+                HU[53] = pl < 0 ? X[53] : cneg(X[53]);
+                c32 NH[64];
+                for (int i = 6; i <= 58; i++) {
+                    if (i == 32) continue;
+                    c32 sum = { 0.0f, 0.0f };
+                    int cnt = 0;
+                    for (int k = i - 2; k <= i + 2; k++) {
+                        if (k == 32 || k < 6 || k > 58) continue;
+                        sum = cnt ? cadd(sum, HU[k]) : HU[k];
+                        cnt++;
+                    }
+                    NH[i].re = 0.5f * DH[i].re + 0.5f * (sum.re / (float)cnt);
+                    NH[i].im = 0.5f * DH[i].im + 0.5f * (sum.im / (float)cnt);
+                }
+                for (int i = 6; i <= 58; i++) if (i != 32) DH[i] = NH[i];
             }
             if (s == 2) {
                 /* (7) SIGNAL field */

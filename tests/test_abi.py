@@ -58,7 +58,7 @@ def test_create_argument_checks():
     h = ctypes.c_void_p()
     bad = capi.Config(99, 0, 20e6, 5.89e9, 0.56, 2, 0, 64, 0, 0, 0, 0)
     assert capi.lib().wifirx_create(ctypes.byref(bad), ctypes.byref(h)) == -1
-    for kw in (dict(max_sym=0), dict(max_sym=512), dict(llr_bits=3), dict(chan_est=2), dict(chan_est=3), dict(bandwidth=0.0)):
+    for kw in (dict(max_sym=0), dict(max_sym=512), dict(llr_bits=3), dict(chan_est=4), dict(chan_est=-1), dict(bandwidth=0.0)):
         vals = dict(abi_version=2, device=0, bandwidth=20e6, frequency=5.89e9, sensitivity=0.56, min_plateau=2,
                     chan_est=0, max_sym=64, llr_bits=0, want_carrier=0, max_batch=0, max_slot_len=0)
         vals.update(kw)

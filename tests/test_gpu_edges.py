@@ -36,9 +36,9 @@ def test_empty_batch_and_argument_errors():
     with pytest.raises(capi.WifiRxError):
         rx.set_param(99, 1.0)
     with pytest.raises(capi.WifiRxError):
-        rx.set_param(capi.P_CHAN_EST, capi.EQ_STA)
-    rx.set_param(capi.P_CHAN_EST, capi.EQ_LMS)
-    rx.set_param(capi.P_CHAN_EST, capi.EQ_LS)
+        rx.set_param(capi.P_CHAN_EST, 4)
+    for eq in (capi.EQ_STA, capi.EQ_COMB, capi.EQ_LMS, capi.EQ_LS):
+        rx.set_param(capi.P_CHAN_EST, eq)
     st = rx.stats()
     assert st["samples_in"] == 0
     rx.close()

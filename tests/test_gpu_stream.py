@@ -97,6 +97,7 @@ def test_block_publishes_reference_pdus(orc):
     n_sym_total = sum(txgen.n_sym_for(len(r), e) for r, e in zip(psdus, [0, 2, 4, 7, 2, 5, 3, 6, 1, 2]))
     assert len(got_car) >= n_sym_total and got_car[0][0] == {} and got_car[0][1].shape == (48,)
     rx.set_frequency(2.6e9); rx.set_bandwidth(10e6); rx.set_sensitivity(0.6)
-    rx.set_chan_est(block.LMS); rx.set_chan_est(block.LS)
+    for eq in (block.LMS, block.COMB, block.STA, block.LS):
+        rx.set_chan_est(eq)
     with pytest.raises(Exception):
-        rx.set_chan_est(block.STA)
+        rx.set_chan_est(7)

@@ -1,4 +1,4 @@
-"""Row f4 (partly): the LMS equaliser (ieee802_11.LMS, gnu_radio/IRS_AP.py:139-141) and the CSI export."""
+"""Row f4: the LMS equaliser (ieee802_11.LMS, gnu_radio/IRS_AP.py:139-141) and the CSI export."""
 import numpy as np
 import pytest
 
