@@ -36,10 +36,13 @@ namespace wr {
 #define WR_DEC_CHUNK      60                   // trellis steps per gathered mask word (10 groups of 6)
 #define WR_DEC_LDS_WORDS  (4 * WR_DECODE_FRAMES_PER_WAVE)   // per wave, 8-byte words: [A1,AV,B1,BV][frame] of the current chunk
 
-// the coded bit at position `ci` of the de-punctured stream of a frame: 0/1, or 2 when punctured.
+// Where the coded bit at position `ci` of the de-punctured stream of ONE OFDM symbol comes from: carrier (bits 0..5)
+// and bit of its decision (bits 6..8), or WR_SRC_PUNCT when the transmitter dropped it.  Every symbol carries
+// 2 * n_dbps de-punctured positions and exactly n_cbps transmitted bits, so the map repeats from symbol to symbol.
 // Rate parameters are template constants: every division below is by a compile-time constant.
+#define WR_SRC_PUNCT 0x200u
 template <int PUNCT, int N_BPSC>
-__device__ __forceinline__ int coded_bit(const uint8_t* __restrict__ idx, int ci)
+__device__ __forceinline__ uint32_t coded_src(int ci)
 {
     constexpr int n_cbps = 48 * N_BPSC;
     constexpr int s = (N_BPSC / 2) < 1 ? 1 : (N_BPSC / 2);
@@ -48,32 +51,63 @@ __device__ __forceinline__ int coded_bit(const uint8_t* __restrict__ idx, int ci
         pidx = ci;
     } else if (PUNCT == 1) {               // 2/3: every 4th bit dropped
         int r = ci & 3;
-        if (r == 3) return 2;
+        if (r == 3) return WR_SRC_PUNCT;
         pidx = (ci >> 2) * 3 + r;
     } else {                               // 3/4: bits 3,4 of every 6 dropped
         int g = ci / 6, r = ci - 6 * g;
-        if (r == 3 || r == 4) return 2;
+        if (r == 3 || r == 4) return WR_SRC_PUNCT;
         pidx = g * 4 + (r < 3 ? r : 3);
     }
-    int sym = pidx / n_cbps, k = pidx - sym * n_cbps;
+    const int k = pidx;                    // < n_cbps: first symbol
     int i = (n_cbps >> 4) * (k & 15) + (k >> 4);
     int j = s * (i / s) + (i + n_cbps - (16 * i) / n_cbps) % s;
     int carrier = j / N_BPSC, bit = j - carrier * N_BPSC;
-    return (idx[sym * 48 + carrier] >> bit) & 1;
+    return (uint32_t)carrier | ((uint32_t)bit << 6);
 }
 
-// gathers one chunk (lane <-> step t0 + lane) of one frame into the four mask words
-template <int PUNCT, int N_BPSC>
-__device__ __forceinline__ void gather_chunk(const uint8_t* __restrict__ fidx, int t, bool in_range,
-                                             uint64_t& A1, uint64_t& AV, uint64_t& B1, uint64_t& BV)
+__device__ __forceinline__ uint32_t coded_src_of(int enc, int ci)
 {
-    int ra = 2, rb = 2;
-    if (in_range) {
-        ra = coded_bit<PUNCT, N_BPSC>(fidx, 2 * t);
-        rb = coded_bit<PUNCT, N_BPSC>(fidx, 2 * t + 1);
+    switch (enc) {
+    case 0:  return coded_src<0, 1>(ci);
+    case 1:  return coded_src<2, 1>(ci);
+    case 2:  return coded_src<0, 2>(ci);
+    case 3:  return coded_src<2, 2>(ci);
+    case 4:  return coded_src<0, 4>(ci);
+    case 5:  return coded_src<2, 4>(ci);
+    case 6:  return coded_src<1, 6>(ci);
+    default: return coded_src<2, 6>(ci);
     }
-    A1 = __ballot(ra == 1); AV = __ballot(ra != 2);
-    B1 = __ballot(rb == 1); BV = __ballot(rb != 2);
+}
+
+#define WR_DEC_TAB_STRIDE 216              // steps per OFDM symbol at the highest rate
+// the workgroup's source table: entry [enc][tt] = source of coded bit A (low half) and B (high half) of step tt
+__device__ __forceinline__ void build_src_table(uint32_t* tab)
+{
+    const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
+    for (int e = threadIdx.x; e < 8 * WR_DEC_TAB_STRIDE; e += blockDim.x) {
+        const int enc = e / WR_DEC_TAB_STRIDE, tt = e - enc * WR_DEC_TAB_STRIDE;
+        uint32_t v = WR_SRC_PUNCT | (WR_SRC_PUNCT << 16);
+        if (tt < ndbps_tab[enc]) v = coded_src_of(enc, 2 * tt) | (coded_src_of(enc, 2 * tt + 1) << 16);
+        tab[e] = v;
+    }
+}
+
+// The received value (0, 1, or 2 = punctured / beyond the tile) of the coded bits A and B of step t of one frame.
+// `tile` holds the decisions of the symbols sym0.. of the frame (48 bytes each, LDS); n_dbps and its reciprocal
+// (ceil(2^32 / n_dbps): exact quotients for every t < 2^17) are wave-uniform.
+__device__ __forceinline__ void gather_step(const uint8_t* tile, int sym0, const uint32_t* __restrict__ tab_enc,
+                                            int n_dbps, uint32_t recip, int t, bool in_range, int& ra, int& rb)
+{
+    ra = 2; rb = 2;
+    if (in_range) {
+        const int sym = (int)__umulhi((uint32_t)t, recip);
+        const int tt = t - sym * n_dbps;
+        const uint32_t e = tab_enc[tt];
+        const uint32_t ea = e & 0xffffu, eb = e >> 16;
+        const uint8_t* sp = tile + (sym - sym0) * 48;
+        if (!(ea & WR_SRC_PUNCT)) ra = (sp[ea & 63u] >> (ea >> 6)) & 1;
+        if (!(eb & WR_SRC_PUNCT)) rb = (sp[eb & 63u] >> (eb >> 6)) & 1;
+    }
 }
 
 constexpr __host__ __device__ int rotr6(int s, int p) { return ((s >> p) | (s << (6 - p))) & 63; }
@@ -124,8 +158,10 @@ __device__ __forceinline__ uint32_t crc32_bit(uint32_t c, uint32_t bit)
 }
 
 // descramble (x^7+x^4+1, state from the first 7 decoded bits), bytes, CRC-32 of one frame; db = its decoded words
+// (stride 128 dwords, two spare words behind the last one).  The next word is fetched while the current one is
+// consumed; PSDU bytes leave four at a time when the row is dword-aligned (wave-uniform `dword_ok`).
 __device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, int psdu_len, uint8_t* __restrict__ psdu,
-                                             wifirx_frame* __restrict__ rec, uint32_t flags)
+                                             bool dword_ok, wifirx_frame* __restrict__ rec, uint32_t flags)
 {
     uint32_t w0 = db[0];
     int state = 0;
@@ -137,21 +173,28 @@ __device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, in
         state = ((state << 1) & 0x7e) | fb;
     }
     uint32_t crc = 0xffffffffu;
-    uint32_t cur = w0;
+    uint32_t cur = w0, nxt = db[128];
     int wi = 0;
+    uint32_t quad = 0;
     for (int b = 0; b < psdu_len; b++) {
         uint32_t byte = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int i = 16 + 8 * b + k;
-            if ((i >> 5) != wi) { wi = i >> 5; cur = db[(size_t)wi * 128]; }
+            if ((i >> 5) != wi) { wi = i >> 5; cur = nxt; nxt = db[(size_t)(wi + 1) * 128]; }
             const uint32_t fb = (uint32_t)(((state >> 6) ^ (state >> 3)) & 1);
             state = ((state << 1) & 0x7e) | (int)fb;
             const uint32_t d = ((cur >> (i & 31)) & 1u) ^ fb;
             byte |= d << k;
             crc = crc32_bit(crc, d);
         }
-        psdu[b] = (uint8_t)byte;
+        if (dword_ok) {
+            quad |= byte << (8 * (b & 3));
+            if ((b & 3) == 3) { *reinterpret_cast<uint32_t*>(psdu + b - 3) = quad; quad = 0; }
+            else if (b == psdu_len - 1) { for (int k = 0; k <= (b & 3); k++) psdu[b - (b & 3) + k] = (uint8_t)(quad >> (8 * k)); }
+        } else {
+            psdu[b] = (uint8_t)byte;
+        }
     }
     crc = ~crc;
     uint32_t fl = flags | WIFIRX_F_DECODED;
@@ -165,6 +208,9 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                    uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total)
 {
     __shared__ uint64_t lds_all[4][WR_DEC_LDS_WORDS];
+    __shared__ uint32_t src_tab[8 * WR_DEC_TAB_STRIDE];
+    build_src_table(src_tab);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * 4 + wv;
@@ -177,6 +223,10 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
     const uint32_t k15 = 0x000f000fu, k2 = 0x00020002u, k1 = 0x00010001u;
 
     const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
+#define WR_RECIP32(d) (uint32_t)((0x100000000ull + (d) - 1) / (d))      /* ceil(2^32 / d) */
+    const uint32_t recip_tab[8] = { WR_RECIP32(24), WR_RECIP32(36), WR_RECIP32(48), WR_RECIP32(72),
+                                    WR_RECIP32(96), WR_RECIP32(144), WR_RECIP32(192), WR_RECIP32(216) };
+#undef WR_RECIP32
 
     for (uint32_t base = wave * WR_DECODE_FRAMES_PER_WAVE; base < n_slots; base += n_waves_total * WR_DECODE_FRAMES_PER_WAVE) {
         // ---- my two frames ----
@@ -206,30 +256,44 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
         const uint64_t valid_mask[2] = { __ballot(n_data[0] > 0), __ballot(n_data[1] > 0) };
 
         // ---- phase 1: gather the received coded bits of every frame, one frame at a time, lane <-> step, into the
-        //      wave's mask area [chunk][A1,AV,B1,BV][frame] (global scratch; nothing else is live in registers here) ----
+        //      wave's mask area [chunk][A1,AV,B1,BV][frame] (global scratch; nothing else is live in registers here).
+        //      The decisions of a frame come in tiles of 60 OFDM symbols, copied into the wave's LDS by coalesced
+        //      16-byte loads: one global round trip per tile instead of one per chunk (60 symbols hold a whole
+        //      number of 60-step chunks at every rate) ----
+        uint8_t* tile = reinterpret_cast<uint8_t*>(lds);
+        const bool idx16 = ((reinterpret_cast<uintptr_t>(idx_all) | ((size_t)max_sym * 48)) & 15) == 0;
         for (int f = 0; f < WR_DECODE_FRAMES_PER_WAVE; f++) {
             const int fh = f >> 6, fl = f & 63;
             if (!((valid_mask[fh] >> fl) & 1)) continue;
             const int f_enc = __builtin_amdgcn_readlane(fh ? enc[1] : enc[0], fl);
             const int f_ndata = __builtin_amdgcn_readlane(fh ? n_data[1] : n_data[0], fl);
             const uint8_t* fidx = idx_all + (size_t)(base + f) * max_sym * 48;
-            for (int c = 0; c * WR_DEC_CHUNK < f_ndata; c++) {
-                const int t = c * WR_DEC_CHUNK + lane;
-                const bool in_range = lane < WR_DEC_CHUNK && t < f_ndata;
-                uint64_t A1, AV, B1, BV;
-                switch (f_enc) {
-                case 0:  gather_chunk<0, 1>(fidx, t, in_range, A1, AV, B1, BV); break;
-                case 1:  gather_chunk<2, 1>(fidx, t, in_range, A1, AV, B1, BV); break;
-                case 2:  gather_chunk<0, 2>(fidx, t, in_range, A1, AV, B1, BV); break;
-                case 3:  gather_chunk<2, 2>(fidx, t, in_range, A1, AV, B1, BV); break;
-                case 4:  gather_chunk<0, 4>(fidx, t, in_range, A1, AV, B1, BV); break;
-                case 5:  gather_chunk<2, 4>(fidx, t, in_range, A1, AV, B1, BV); break;
-                case 6:  gather_chunk<1, 6>(fidx, t, in_range, A1, AV, B1, BV); break;
-                default: gather_chunk<2, 6>(fidx, t, in_range, A1, AV, B1, BV); break;
+            const int f_ndbps = ndbps_tab[f_enc];
+            const uint32_t f_recip = recip_tab[f_enc];
+            const int f_nsym = f_ndata / f_ndbps;
+            for (int sym0 = 0; sym0 < f_nsym; sym0 += 60) {
+                const int nsy = f_nsym - sym0 < 60 ? f_nsym - sym0 : 60;
+                const int nbytes = nsy * 48;
+                __builtin_amdgcn_wave_barrier();
+                if (idx16) {
+                    for (int o = lane * 16; o < nbytes; o += 1024)
+                        *reinterpret_cast<uint4*>(tile + o) = *reinterpret_cast<const uint4*>(fidx + sym0 * 48 + o);
+                } else {
+                    for (int o = lane; o < nbytes; o += 64) tile[o] = fidx[sym0 * 48 + o];
                 }
-                if (lane < 4) {
-                    uint64_t wsel = lane == 0 ? A1 : lane == 1 ? AV : lane == 2 ? B1 : BV;
-                    masks[((size_t)c * 4 + lane) * WR_DECODE_FRAMES_PER_WAVE + f] = wsel;
+                __builtin_amdgcn_wave_barrier();
+                const int t_hi = (sym0 + nsy) * f_ndbps;
+                for (int c = sym0 * f_ndbps / WR_DEC_CHUNK; c * WR_DEC_CHUNK < t_hi; c++) {
+                    const int t = c * WR_DEC_CHUNK + lane;
+                    int ra, rb;
+                    gather_step(tile, sym0, src_tab + f_enc * WR_DEC_TAB_STRIDE, f_ndbps, f_recip, t,
+                                lane < WR_DEC_CHUNK && t < t_hi, ra, rb);
+                    const uint64_t A1 = __ballot(ra == 1), AV = __ballot(ra != 2);
+                    const uint64_t B1 = __ballot(rb == 1), BV = __ballot(rb != 2);
+                    if (lane < 4) {
+                        uint64_t wsel = lane == 0 ? A1 : lane == 1 ? AV : lane == 2 ? B1 : BV;
+                        masks[((size_t)c * 4 + lane) * WR_DECODE_FRAMES_PER_WAVE + f] = wsel;
+                    }
                 }
             }
         }
@@ -310,22 +374,22 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
         }
         __threadfence_block();
         // ---- traceback of both frames: 32 decoded bits per word, words stored [word][A/B][lane].  The survivor
-        //      row of a step does not depend on the path (only the piece picked from it does), so eight rows are
-        //      loaded ahead of the eight dependent state updates: one memory round trip per eight steps ----
+        //      row of a step does not depend on the path (only the piece picked from it does), so sixteen rows are
+        //      loaded ahead of the sixteen dependent state updates: one memory round trip per sixteen steps ----
         {
             int st0 = best[0], st1 = best[1];
             uint32_t word0 = 0, word1 = 0;
-            for (int t1 = n_max - 1; t1 >= 0; t1 -= 8) {
-                uint4 rows[8];
+            for (int t1 = n_max - 1; t1 >= 0; t1 -= 16) {
+                uint4 rows[16];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < 16; k++) {
                     const int t = t1 - k;
                     rows[k] = make_uint4(0u, 0u, 0u, 0u);
                     if (t >= 0 && (t < n_data[0] || t < n_data[1]))
                         rows[k] = *reinterpret_cast<const uint4*>(surv + ((size_t)t * 64 + lane) * 4);
                 }
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < 16; k++) {
                     const int t = t1 - k;
                     const bool mine0 = t >= 0 && t < n_data[0], mine1 = t >= 0 && t < n_data[1];
                     const int i0 = st0 >> 4, i1 = st1 >> 4;
@@ -352,7 +416,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
             if (n_data[h] > 0) {                               // the record is re-read: nothing of it was kept in registers
                 const uint32_t slot = base + 64 * h + lane;
                 finish_frame(dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
-                             frames + slot, frames[slot].flags);
+                             ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags);
             }
         }
     }
