@@ -219,7 +219,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
     const size_t n_data_cap = n_steps_cap;               // trellis steps the scratch slice of a wave holds
     uint32_t* surv = reinterpret_cast<uint32_t*>(scratch + (size_t)wave * scratch_stride);   // [step][lane][4 pieces]
     uint32_t* dbits = surv + n_data_cap * 256;                                               // [word][A/B][lane]
-    uint64_t* masks = reinterpret_cast<uint64_t*>(dbits + (n_data_cap / 32 + 2) * WR_DECODE_FRAMES_PER_WAVE);   // [chunk][4][frame]
+    uint64_t* masks_base = reinterpret_cast<uint64_t*>(dbits + (n_data_cap / 32 + 2) * WR_DECODE_FRAMES_PER_WAVE);   // 2 x [chunk][4][frame]
     const uint32_t k15 = 0x000f000fu, k2 = 0x00020002u, k1 = 0x00010001u;
 
     const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
@@ -228,7 +228,22 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                                     WR_RECIP32(96), WR_RECIP32(144), WR_RECIP32(192), WR_RECIP32(216) };
 #undef WR_RECIP32
 
-    for (uint32_t base = wave * WR_DECODE_FRAMES_PER_WAVE; base < n_slots; base += n_waves_total * WR_DECODE_FRAMES_PER_WAVE) {
+    // A wave's tasks (128 frames each, grid-stride).  The gather and the traceback/CRC phases wait on memory, the
+    // add-compare-select phase keeps the vector ALU busy; waves that walk their phases in step leave the ALU idle
+    // while all of them wait.  So the workgroups alternate between two orders: even ones gather a task right before
+    // decoding it (G0 R0 G1 R1 ...), odd ones keep the gather one task ahead (G0 G1 R0 G2 R1 ...), with two mask
+    // buffers -- the waves that share a SIMD come from different workgroups and now overlap their phases.
+    const uint32_t task_stride = n_waves_total * WR_DECODE_FRAMES_PER_WAVE;
+    const uint32_t first = wave * WR_DECODE_FRAMES_PER_WAVE;
+    const int n_tasks = first < n_slots ? (int)((n_slots - first + task_stride - 1) / task_stride) : 0;
+    const int lead = ((blockIdx.x >> 8) & 1) ? 2 : 1;      // workgroups i, i + 256, ... tend to share a CU
+    const size_t masks_words = ((size_t)n_data_cap / WR_DEC_CHUNK + 2) * 4 * WR_DECODE_FRAMES_PER_WAVE;
+    for (int gi = 0, ri = 0; ri < n_tasks;) {
+        const bool do_gather = gi < n_tasks && gi - ri < lead;
+        const int task = do_gather ? gi : ri;
+        const uint32_t base = first + (uint32_t)task * task_stride;
+        uint64_t* masks = masks_base + (size_t)(task & 1) * masks_words;
+        if (do_gather) gi++; else ri++;
         // ---- my two frames ----
         int enc[2], n_data[2];
         int n_max = 0;
@@ -254,6 +269,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
         }
         if (n_max == 0) continue;
         const uint64_t valid_mask[2] = { __ballot(n_data[0] > 0), __ballot(n_data[1] > 0) };
+        if (do_gather) {
 
         // ---- phase 1: gather the received coded bits of every frame, one frame at a time, lane <-> step, into the
         //      wave's mask area [chunk][A1,AV,B1,BV][frame] (global scratch; nothing else is live in registers here).
@@ -298,6 +314,8 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
             }
         }
         __threadfence_block();
+        continue;
+        }
 
         // ---- phase 2: add-compare-select ----
         uint32_t pm[64];
