@@ -74,3 +74,36 @@ def test_full_size_properties():
     r2 = rx.download_out(dev2, n // 2)
     assert np.array_equal(r2["idx"], r["idx"][n // 2:]) and np.array_equal(r2["llr"], r["llr"][n // 2:])
     rx.free_out(dev); rx.free_out(dev2); slots.free(); rx.close()
+
+
+def test_decode_with_unaligned_buffers(orc):
+    """decode_mac's fast paths (16-byte tile copies of the decisions, dword PSDU stores) are taken only when the
+    caller's buffers allow it: an odd PSDU stride and a decisions buffer that is merely 4-byte aligned must give
+    the same bytes"""
+    from helpers import make_slots
+    from wifirx import capi
+    C = capi.C
+    iq, slot_len, tx = make_slots(150, 5, snr_db=26.0, seed=21, psdu_len=333)
+    n = 150
+    rx = capi.WifiRx(max_sym=tx.n_sym)
+    d_iq = rx.alloc(iq.nbytes).upload(iq)
+    d_fr, d_idx = rx.alloc(n * 32), rx.alloc(n * tx.n_sym * 48 + 64)
+    stride = 337
+    d_psdu = rx.alloc(n * stride + 64)
+    for b in (d_fr, d_idx, d_psdu):
+        b.upload(np.zeros(b.nbytes, np.uint8))
+    out = capi.Out(d_fr.ptr, d_idx.ptr + 4, None, None, d_psdu.ptr + 1, stride, 1, None)
+    rx._check(capi.lib().wifirx_demod_batch(rx._h, d_iq.ptr, 1, slot_len, n, C.byref(out)))
+    rx._check(capi.lib().wifirx_decode_batch(rx._h, n, C.byref(out)))
+    rx.sync()
+    fr = d_fr.download(capi.FRAME_DTYPE, n)
+    psdu = d_psdu.download(np.uint8, n * stride + 1)[1:].reshape(n, stride)
+    prm = orc.make_params(max_sym=tx.n_sym)
+    o = orc.demod_batch(iq, slot_len, prm)
+    opsdu = orc.decode_batch(o["frames"], o["idx"], prm, psdu_stride=stride)
+    assert np.array_equal(fr, o["frames"])
+    assert (fr["flags"] & capi.F_CRC_OK).all()
+    assert np.array_equal(psdu[:, :333], opsdu[:, :333]) and np.array_equal(psdu[:, :333], tx.psdu)
+    for b in (d_iq, d_fr, d_idx, d_psdu):
+        b.free()
+    rx.close()
