@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <new>
@@ -47,6 +49,8 @@ struct wifirx_handle {
     // decode workspace
     void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;
     void*  dec_max = nullptr;       size_t dec_max_bytes = 0;
+    void*  s_pack = nullptr;        size_t s_pack_bytes = 0;      // stream outputs, rows cut to their filled width
+    void*  s_host = nullptr;        size_t s_host_bytes = 0;      // pinned landing zone of the packed outputs
 
     // stream mode
     float2*  sbuf = nullptr;        int64_t sbuf_cap = 0;     // device sample buffer
@@ -85,6 +89,17 @@ int ensure(wifirx_handle* h, void** p, size_t* have, size_t need)
     if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
     hipError_t e = hipMalloc(p, need);
     if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    *have = need;
+    return WIFIRX_OK;
+}
+
+int ensure_pinned(wifirx_handle* h, void** p, size_t* have, size_t need)
+{
+    if (*have >= need) return WIFIRX_OK;
+    if (*p) { (void)hipHostFree(*p); *p = nullptr; *have = 0; }
+    need += need / 2;
+    hipError_t e = hipHostMalloc(p, need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     *have = need;
     return WIFIRX_OK;
 }
@@ -152,6 +167,8 @@ int wifirx_destroy(wifirx_handle* h)
                      h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx, h->s_llr,
                      h->s_car, h->s_psdu };
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (h->s_pack) (void)hipFree(h->s_pack);
+    if (h->s_host) (void)hipHostFree(h->s_host);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return WIFIRX_OK;

@@ -205,7 +205,8 @@ __device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, in
 __global__ __launch_bounds__(256, WR_DEC_WAVES_PER_SIMD)
 void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
                    const uint8_t* __restrict__ idx_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
-                   uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total)
+                   uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total,
+                   uint32_t frames_per_wave)
 {
     __shared__ uint64_t lds_all[4][WR_DEC_LDS_WORDS];
     __shared__ uint32_t src_tab[8 * WR_DEC_TAB_STRIDE];
@@ -233,8 +234,12 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
     // while all of them wait.  So the workgroups alternate between two orders: even ones gather a task right before
     // decoding it (G0 R0 G1 R1 ...), odd ones keep the gather one task ahead (G0 G1 R0 G2 R1 ...), with two mask
     // buffers -- the waves that share a SIMD come from different workgroups and now overlap their phases.
-    const uint32_t task_stride = n_waves_total * WR_DECODE_FRAMES_PER_WAVE;
-    const uint32_t first = wave * WR_DECODE_FRAMES_PER_WAVE;
+    // frames_per_wave <= 128: a small batch is spread over more waves (fewer frames each: the gather is per frame and
+    // the butterflies cost the same whatever the number of active lanes, so this only shortens the latency).
+    // Lane l owns frames base + l (l < fA) and base + fA + l (l < fB).
+    const uint32_t fA = frames_per_wave < 64 ? frames_per_wave : 64, fB = frames_per_wave - fA;
+    const uint32_t task_stride = n_waves_total * frames_per_wave;
+    const uint32_t first = wave * frames_per_wave;
     const int n_tasks = first < n_slots ? (int)((n_slots - first + task_stride - 1) / task_stride) : 0;
     const int lead = ((blockIdx.x >> 8) & 1) ? 2 : 1;      // workgroups i, i + 256, ... tend to share a CU
     const size_t masks_words = ((size_t)n_data_cap / WR_DEC_CHUNK + 2) * 4 * WR_DECODE_FRAMES_PER_WAVE;
@@ -249,14 +254,15 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
         int n_max = 0;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const uint32_t slot = base + 64 * h + lane;
+            const uint32_t slot = base + (h ? fA : 0u) + lane;
+            const bool mine = (uint32_t)lane < (h ? fB : fA) && slot < n_slots;
             uint32_t flags = 0;
             int len = 0;
             enc[h] = 0;
-            if (slot < n_slots) { flags = frames[slot].flags; enc[h] = frames[slot].encoding & 7; len = frames[slot].psdu_len; }
+            if (mine) { flags = frames[slot].flags; enc[h] = frames[slot].encoding & 7; len = frames[slot].psdu_len; }
             const int n_dbps = ndbps_tab[enc[h]];
             const int n_sym = (16 + 8 * len + 6 + n_dbps - 1) / n_dbps;
-            const bool ok = slot < n_slots && (flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride &&
+            const bool ok = mine && (flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride &&
                             len <= WIFIRX_MAX_PSDU && n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym &&
                             (uint32_t)(n_sym * n_dbps) <= n_steps_cap;
             n_data[h] = ok ? n_sym * n_dbps : 0;                // multiple of 12; 0: nothing to decode
@@ -283,7 +289,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
             if (!((valid_mask[fh] >> fl) & 1)) continue;
             const int f_enc = __builtin_amdgcn_readlane(fh ? enc[1] : enc[0], fl);
             const int f_ndata = __builtin_amdgcn_readlane(fh ? n_data[1] : n_data[0], fl);
-            const uint8_t* fidx = idx_all + (size_t)(base + f) * max_sym * 48;
+            const uint8_t* fidx = idx_all + (size_t)(base + (fh ? fA : 0u) + fl) * max_sym * 48;
             const int f_ndbps = ndbps_tab[f_enc];
             const uint32_t f_recip = recip_tab[f_enc];
             const int f_nsym = f_ndata / f_ndbps;
@@ -432,7 +438,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (n_data[h] > 0) {                               // the record is re-read: nothing of it was kept in registers
-                const uint32_t slot = base + 64 * h + lane;
+                const uint32_t slot = base + (h ? fA : 0u) + lane;
                 finish_frame(dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
                              ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags);
             }
@@ -479,11 +485,11 @@ extern "C" hipError_t wr_launch_decode_maxsteps(hipStream_t st, uint32_t n_slots
 
 extern "C" hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                                        const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
-                                       size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves)
+                                       size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave)
 {
     if (n_slots == 0 || n_waves == 0) return hipSuccess;
     uint32_t blocks = (n_waves + 3) / 4;
     hipLaunchKernelGGL(wr::decode_kernel, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, idx, psdu,
-                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves);
+                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave);
     return hipGetLastError();
 }

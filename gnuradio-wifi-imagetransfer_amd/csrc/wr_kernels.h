@@ -48,7 +48,7 @@ hipError_t wr_launch_decode_maxsteps(hipStream_t st, uint32_t n_slots, uint32_t 
                                      const wifirx_frame* frames, uint32_t psdu_stride, uint32_t* out);
 hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                             const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
-                            size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves);
+                            size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave);
 hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_samp, int64_t tile0,
                                    int64_t n_tiles, float thr, uint64_t* masks, float2* A);
 hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
