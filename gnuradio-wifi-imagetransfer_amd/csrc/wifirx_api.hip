@@ -58,6 +58,8 @@ struct wifirx_handle {
     int64_t  sfill = 0;             // valid samples in sbuf
     int64_t  sdetected = 0;         // absolute index up to which triggers have been selected
     int64_t  last_trig = -(1ll << 40);
+    int64_t  stream_batch = 0;      // WIFIRX_P_STREAM_BATCH
+    int64_t  sprocessed = 0;        // absolute index up to which pushes have been processed
     uint8_t* s_above = nullptr;     float2* s_A = nullptr;    int64_t s_above_cap = 0;
     std::vector<PendingTrig> pending;
     std::deque<PolledFrame>  queue;
@@ -193,6 +195,10 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
         if ((int)value < WIFIRX_EQ_LS || (int)value > WIFIRX_EQ_STA)
             return fail(h, WIFIRX_EINVAL, "chan_est must be one of WIFIRX_EQ_LS, LMS, COMB, STA");
         h->cfg.chan_est = (int)value;
+        return WIFIRX_OK;
+    case WIFIRX_P_STREAM_BATCH:
+        if (!(value >= 0) || value > 1e9) return fail(h, WIFIRX_EINVAL, "stream batch out of range");
+        h->stream_batch = (int64_t)value;
         return WIFIRX_OK;
     default:
         return fail(h, WIFIRX_EINVAL, "unknown parameter id");

@@ -31,7 +31,7 @@ LINKTYPE_IEEE802_11 = 105
 
 class wifi_phy_rx(grshim.sync_block):
     def __init__(self, bandwidth=10e6, chan_est=LS, encoding=0, frequency=5.89e9, sensitivity=0.56,
-                 max_sym=511, publish_carrier=True, device=0):
+                 max_sym=511, publish_carrier=True, device=0, batch_samples=1 << 20):
         grshim.sync_block.__init__(self, name="wifi_phy_rx", in_sig=[np.complex64], out_sig=None)
         self.bandwidth = float(bandwidth)
         self.chan_est = int(chan_est)
@@ -44,6 +44,10 @@ class wifi_phy_rx(grshim.sync_block):
         self._rx = capi.WifiRx(bandwidth=self.bandwidth, frequency=self.frequency, sensitivity=self.sensitivity,
                                chan_est=self.chan_est, max_sym=max_sym, llr_bits=0,
                                want_carrier=self.publish_carrier, device=device)
+        # The scheduler calls work() with a few thousand items; the GPU pipeline runs once `batch_samples` have come in
+        # (about 50 ms of signal at 20 MS/s) -- one device round trip per work() call could not keep up -- and at stop().
+        self.batch_samples = int(batch_samples)
+        self._rx.set_param(capi.P_STREAM_BATCH, self.batch_samples)
         self.frames_ok = 0
         self.frames_dropped = 0
 

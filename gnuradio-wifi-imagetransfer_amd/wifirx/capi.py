@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WIFIRX_LIB") or os.path.join(_HERE, "libwifirx.so")  
 
 ABI_VERSION = 2
 EQ_LS, EQ_LMS, EQ_COMB, EQ_STA = 0, 1, 2, 3
-P_BANDWIDTH, P_FREQUENCY, P_SENSITIVITY, P_CHAN_EST = 1, 2, 3, 4
+P_BANDWIDTH, P_FREQUENCY, P_SENSITIVITY, P_CHAN_EST, P_STREAM_BATCH = 1, 2, 3, 4, 5
 F_DETECTED, F_SYNC, F_SIGNAL, F_COMPLETE, F_LLR, F_DECODED, F_CRC_OK = 1, 2, 4, 8, 16, 32, 64
 
 FRAME_DTYPE = np.dtype([
@@ -268,14 +268,19 @@ class WifiRx:
         self._check(_lib.wifirx_push(self._h, _np_ptr(iq), iq.size, 0))
 
     def poll(self, cap=256, psdu_stride=2048, want_idx=False):
+        """Finished frames of the stream, oldest first (at most `cap`).  The landing buffers are kept between calls
+        (a scheduler polls after every work()); what is returned are copies of the filled part."""
         ms = self.cfg.max_sym
-        frames = np.zeros(cap, dtype=FRAME_DTYPE)
-        psdu = np.zeros((cap, psdu_stride), dtype=np.uint8)
-        idx = np.zeros((cap, ms, 48), dtype=np.uint8) if want_idx else None
-        car = np.zeros((cap, ms, 48), dtype=np.complex64) if self.cfg.want_carrier else None
+        key = (cap, psdu_stride, bool(want_idx))
+        if getattr(self, "_poll_key", None) != key:
+            self._poll_key = key
+            self._poll_buf = (np.zeros(cap, dtype=FRAME_DTYPE), np.zeros((cap, psdu_stride), dtype=np.uint8),
+                              np.zeros((cap, ms, 48), dtype=np.uint8) if want_idx else None,
+                              np.zeros((cap, ms, 48), dtype=np.complex64) if self.cfg.want_carrier else None)
+        frames, psdu, idx, car = self._poll_buf
         n = C.c_uint32(0)
         self._check(_lib.wifirx_poll(self._h, _np_ptr(frames), _np_ptr(psdu), psdu_stride, _np_ptr(idx),
                                      _np_ptr(car), cap, C.byref(n)))
         n = n.value
-        return dict(frames=frames[:n], psdu=psdu[:n], idx=None if idx is None else idx[:n],
-                    carrier=None if car is None else car[:n])
+        return dict(frames=frames[:n].copy(), psdu=psdu[:n].copy(), idx=None if idx is None else idx[:n].copy(),
+                    carrier=None if car is None else car[:n].copy())

@@ -110,6 +110,10 @@ typedef struct wifirx_config {
 #define WIFIRX_P_FREQUENCY   2
 #define WIFIRX_P_SENSITIVITY 3
 #define WIFIRX_P_CHAN_EST    4
+/* stream mode: wifirx_push only collects samples until this many are waiting, then detects / demodulates /
+ * decodes them in one go (0 = on every push).  A GNU Radio scheduler hands work() a few thousand items at a
+ * time; one GPU round trip per such call would not keep up with the sample rate.  A push with n = 0 flushes. */
+#define WIFIRX_P_STREAM_BATCH 5
 
 typedef struct wifirx_handle wifirx_handle;
 

@@ -19,7 +19,8 @@ from wifirx import app, block, grshim, txgen  # noqa: E402
 def main():
     imgs = np.load(os.path.join(ROOT, "tests", "golden", "kodim_300.npz"))
     snr_db = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
-    res = {"snr_db": snr_db, "images": {}, "encoding": "BPSK_1_2"}
+    chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 8192        # items per work() call (GNU Radio hands out thousands)
+    res = {"snr_db": snr_db, "images": {}, "encoding": "BPSK_1_2", "work_chunk": chunk}
     total_samples, total_time = 0, 0.0
     for name in sorted(imgs.files):
         img = imgs[name]
@@ -42,7 +43,7 @@ def main():
         pics = app.extract_pics(sink=got.append)
         grshim.msg_connect(rx, "mac_out", pics, "MAC")
         t = time.perf_counter()
-        grshim.run_stream(rx, x, chunk=1 << 22)
+        grshim.run_stream(rx, x, chunk=chunk)
         dt = time.perf_counter() - t
         out = np.zeros_like(img)
         for g in got:
