@@ -35,17 +35,22 @@ def oracle_stream(orc, x, max_sym=511):
     return o, psdu
 
 
-@pytest.mark.parametrize("chunk", [777, 4096, 100000, 10**7])
+@pytest.mark.parametrize("chunk,batch", [(777, 0), (4096, 0), (100000, 0), (10**7, 0), (777, 20000), (4096, 1 << 20)])
 @pytest.mark.parametrize("noise", [True, False])
-def test_push_poll_matches_oracle_stream(orc, chunk, noise):
+def test_push_poll_matches_oracle_stream(orc, chunk, batch, noise):
+    """chunk = samples per push; batch = WIFIRX_P_STREAM_BATCH (0: process every push; otherwise pushes only collect
+    until that many samples wait): the frames that come out do not depend on either"""
     from wifirx import capi
     x, psdus = build_stream(noise=noise)
     o, opsdu = oracle_stream(orc, x)
     rx = capi.WifiRx(max_sym=511, want_carrier=True)
+    rx.set_param(capi.P_STREAM_BATCH, batch)
     got = []
     for p in range(0, x.size, chunk):
         rx.push(x[p:p + chunk])
         got.append(rx.poll(cap=64, want_idx=True))
+        if batch and p + chunk < batch:
+            assert len(got[-1]["frames"]) == 0          # still collecting
     rx._check(capi.lib().wifirx_push(rx._h, None, 0, 0))       # flush
     got.append(rx.poll(cap=64, want_idx=True))
     frames = np.concatenate([g["frames"] for g in got])
