@@ -115,3 +115,32 @@ def test_llr_signs_reproduce_hard_decisions(orc):
         agree = (llr > 0) == (bits == 1)
         # the sign equals the slicer bit except within an ulp of a slicer boundary
         assert agree.mean() > 0.99999
+
+
+def test_annex_signal_field_encoded_and_interleaved():
+    """IEEE Std 802.11 Annex example (36 Mb/s, LENGTH 100): the SIGNAL field after the convolutional encoder and
+    after the interleaver, as tabulated in the standard -- pins generator order and interleaver of the transmitter
+    the loop-back tests use, independently of this repository's receiver"""
+    b = txgen.signal_bits(5, 100)
+    coded = txgen.conv_encode(b[None])[0]
+    assert "".join(map(str, coded)) == "110100011010000100000010001111100111000000000000"
+    inter = np.empty_like(coded)
+    inter[txgen.interleaver_map(48, 1)] = coded
+    assert "".join(map(str, inter)) == "100101001101000000010100100000110010010010010100"
+
+
+def test_annex_preamble_time_samples():
+    """The standard tabulates the time-domain preamble (three decimals, its own scaling = ours * sqrt(52)/64): first
+    samples of the short training sequence (sample 0 halved by the window), the guard interval of the long one
+    (sample 160 overlaps the short sequence's tail) and the long training symbol itself"""
+    tx = txgen.encode_psdus(txgen.make_psdus(1, 100, seed=1), 5)
+    s = tx.samples[0] * (np.sqrt(52.0) / 64.0)
+    sts = [0.023 + 0.023j, -0.132 + 0.002j, -0.013 - 0.079j, 0.143 - 0.013j, 0.092 + 0.000j,
+           0.143 - 0.013j, -0.013 - 0.079j, -0.132 + 0.002j, 0.046 + 0.046j]
+    gi = [-0.055 + 0.023j, 0.012 - 0.098j, 0.092 - 0.106j, -0.092 - 0.115j, -0.003 - 0.054j,
+          0.075 + 0.074j, -0.127 + 0.021j, -0.122 + 0.017j]
+    lts = [0.156 + 0.000j, -0.005 - 0.120j, 0.040 - 0.111j, 0.097 + 0.083j, 0.021 + 0.028j,
+           0.060 - 0.088j, -0.115 - 0.055j, -0.038 - 0.106j]
+    for off, ref in ((0, sts), (160, gi), (192, lts)):
+        got = s[off:off + len(ref)]
+        assert np.abs(got - np.array(ref)).max() < 7.5e-4, (off, got)
