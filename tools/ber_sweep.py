@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json config 3: 64-QAM-3/4 frames (PSDU 294 B, 11 symbols) through the multipath taps derived from
 the reference's utils/SV_channel.py (tests/golden/sv_taps.npy; the tap construction is a build decision,
-SURVEY.md 8(d)), LS equaliser, SNR 5..30 dB.  Per point: N frames on the GPU, coded-bit BER of the hard
+SURVEY.md 8(d)), LS equaliser (argv[2]: 1 LMS, 2 COMB, 3 STA), SNR 5..30 dB.  Per point: N frames on the GPU, coded-bit BER of the hard
 decisions against the transmitted interleaved bits, frame error rate after decode_mac, and -- on a subset --
 the decision mismatch count against the oracle (must be 0).  One JSON line."""
 import json
@@ -18,6 +18,7 @@ from wifirx import capi, txgen  # noqa: E402
 
 def main():
     n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+    chan_est = int(sys.argv[2]) if len(sys.argv) > 2 else 0            # 0 LS (config 3 proper), 1 LMS, 2 COMB, 3 STA
     n_check = 2000
     taps = np.load(os.path.join(ROOT, "tests", "golden", "sv_taps.npy"))          # [1024, 8]
     n_t = taps.shape[0]
@@ -26,12 +27,12 @@ def main():
     # every template frame goes through its own tap set on the host; noise and CFO are added on the GPU
     faded = txgen.impair(tx.samples, None, cfo=0.0, lead=0, total=tx.samples.shape[1] + 8, taps=taps)
     slot_len, lead = 1472, 160
-    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=0)
+    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=0, chan_est=chan_est)
     slots = rx.alloc(n_frames * slot_len * 8)
     dev = rx.alloc_out(n_frames, psdu_stride=320)
     bits_tx = ((tx.data_idx[..., None] >> np.arange(6)) & 1).astype(np.uint8)
     from oracle import oracle as orc
-    prm = orc.make_params(max_sym=tx.n_sym)
+    prm = orc.make_params(max_sym=tx.n_sym, chan_est=chan_est)
     points = []
     for snr in range(5, 31):
         rx.synth_slots(faded, slots.ptr, slot_len, n_frames, lead, float(snr), 0.037, 1000 + snr)
@@ -56,7 +57,8 @@ def main():
         mism = int(((o["idx"] != r["idx"][:n_check]) & written[..., None]).sum() + (o["frames"] != gfr).sum())
         points.append({"snr_db": snr, "frames": n_frames, "detected_and_signal_ok": float(good.mean()),
                        "coded_ber": ber, "fer": float(1.0 - right.mean()), "oracle_mismatches_on_%d" % n_check: mism})
-    print(json.dumps({"config": "64-QAM 3/4, PSDU 294 B, SV-derived 8-tap Rician channel (K=10), LS equaliser, CFO +-20 ppm",
+    print(json.dumps({"config": "64-QAM 3/4, PSDU 294 B, SV-derived 8-tap Rician channel (K=10), %s equaliser, CFO +-20 ppm"
+                                % ("LS", "LMS", "COMB", "STA")[chan_est],
                       "points": points}))
 
 
