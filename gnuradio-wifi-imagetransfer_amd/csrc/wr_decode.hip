@@ -114,15 +114,15 @@ constexpr __host__ __device__ int rotr6(int s, int p) { return ((s >> p) | (s <<
 constexpr __host__ __device__ int parity_of(int v) { return __builtin_popcount(v) & 1; }
 
 // ---- packed 16-bit arithmetic (both halves at once; the compiler may schedule these freely) ----
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { uint32_t r; asm volatile("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { uint32_t r; asm volatile("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { uint32_t r; asm volatile("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // acc = 2 * acc + (d < 0) per half; k15 = 0x000f000f, k2 = 0x00020002
 __device__ __forceinline__ uint32_t pk_push_sign(uint32_t acc, uint32_t d, uint32_t k15, uint32_t k2)
 {
     uint32_t t, r;
-    asm volatile("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(t) : "v"(k15), "v"(d));
-    asm volatile("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(k2), "v"(t));
+    asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(t) : "v"(k15), "v"(d));
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(k2), "v"(t));
     return r;
 }
 
