@@ -48,6 +48,7 @@ class wifi_phy_rx(grshim.sync_block):
         # (about 50 ms of signal at 20 MS/s) -- one device round trip per work() call could not keep up -- and at stop().
         self.batch_samples = int(batch_samples)
         self._rx.set_param(capi.P_STREAM_BATCH, self.batch_samples)
+        self._pend, self._pend_n = [], 0
         self.frames_ok = 0
         self.frames_dropped = 0
 
@@ -93,13 +94,26 @@ class wifi_phy_rx(grshim.sync_block):
     def work(self, input_items, output_items):
         x = input_items[0]
         n = len(x)
-        if n:
-            self._rx.push(x)
+        if n >= self.batch_samples and not self._pend:
+            self._rx.push(x)                              # a chunk that is a batch by itself goes straight through
             self._publish()
+        elif n:
+            # the scheduler owns the input buffer: keep a copy and hand the library one piece per batch
+            self._pend.append(np.array(x, dtype=np.complex64, copy=True))
+            self._pend_n += n
+            if self._pend_n >= self.batch_samples:
+                self._flush_pending()
+                self._publish()
         return n
+
+    def _flush_pending(self):
+        if self._pend:
+            self._rx.push(self._pend[0] if len(self._pend) == 1 else np.concatenate(self._pend))
+            self._pend, self._pend_n = [], 0
 
     def stop(self):
         """End of stream: settle the frames still waiting for samples."""
+        self._flush_pending()
         self._rx.push(np.zeros(0, dtype=np.complex64))
         self._publish()
         return True
