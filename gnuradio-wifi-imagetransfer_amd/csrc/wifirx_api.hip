@@ -59,6 +59,7 @@ struct wifirx_handle {
     int64_t  sdetected = 0;         // absolute index up to which triggers have been selected
     int64_t  last_trig = -(1ll << 40);
     int64_t  stream_batch = 0;      // WIFIRX_P_STREAM_BATCH
+    uint32_t decode_small_max = WR_DECODE_SMALL_MAX;   // WIFIRX_P_DECODE_SMALL_MAX
     int64_t  sprocessed = 0;        // absolute index up to which pushes have been processed
     uint8_t* s_above = nullptr;     float2* s_A = nullptr;    int64_t s_above_cap = 0;
     std::vector<PendingTrig> pending;
@@ -152,6 +153,7 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
     if (!h) return fail(nullptr, WIFIRX_ENOMEM, "out of host memory");
     h->cfg = *cfg;
     h->device = cfg->device;
+    if (const char* e = std::getenv("WIFIRX_DECODE_SMALL_MAX")) h->decode_small_max = (uint32_t)std::strtoul(e, nullptr, 10);   // tests pick the decode kernel with this
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(nullptr, WIFIRX_EHIP, "hipStreamCreate failed");
@@ -195,6 +197,10 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
         if ((int)value < WIFIRX_EQ_LS || (int)value > WIFIRX_EQ_STA)
             return fail(h, WIFIRX_EINVAL, "chan_est must be one of WIFIRX_EQ_LS, LMS, COMB, STA");
         h->cfg.chan_est = (int)value;
+        return WIFIRX_OK;
+    case WIFIRX_P_DECODE_SMALL_MAX:
+        if (!(value >= 0) || value > 4e9) return fail(h, WIFIRX_EINVAL, "decode threshold out of range");
+        h->decode_small_max = (uint32_t)value;
         return WIFIRX_OK;
     case WIFIRX_P_STREAM_BATCH:
         if (!(value >= 0) || value > 1e9) return fail(h, WIFIRX_EINVAL, "stream batch out of range");

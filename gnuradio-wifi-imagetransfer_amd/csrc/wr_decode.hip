@@ -446,6 +446,166 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The low-latency variant for small batches (stream mode: a few hundred frames per push): one wave per frame,
+// lane <-> trellis state.  An add-compare-select step is two cross-lane reads (ds_bpermute), a handful of vector
+// instructions and one ballot that yields the 64 survivor bits of the step; a frame takes ~0.2 ms instead of the
+// ~4 ms a lone wave of decode_kernel needs for its 2 x 64 frames' worth of butterflies, and hundreds of frames run
+// side by side.  Same metrics, tie rule and final-state rule, hence the same bytes.
+__device__ __forceinline__ uint32_t crc32_update(uint32_t c, uint32_t byte)
+{
+    c ^= byte;
+#pragma unroll
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+    return c;
+}
+
+__global__ __launch_bounds__(256)
+void decode_small_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
+                         const uint8_t* __restrict__ idx_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
+                         uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total)
+{
+    __shared__ uint8_t tile_all[4][60 * 48];
+    __shared__ uint32_t src_tab[8 * WR_DEC_TAB_STRIDE];
+    build_src_table(src_tab);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * 4 + wv;
+    if (wave >= n_waves_total) return;
+    uint8_t* tile = tile_all[wv];
+    uint64_t* dec = reinterpret_cast<uint64_t*>(scratch + (size_t)wave * scratch_stride);     // survivor word per step
+    uint64_t* words = dec + n_steps_cap;                                                      // decoded bits, 60 per word
+
+    // trellis constants of state `lane`: predecessors p0 = s >> 1 and p1 = p0 | 32, input bit s & 1
+    const int s = lane, u = s & 1, p0 = s >> 1, p1 = (s >> 1) | 32;
+    const int f0 = (p0 << 1) | u;
+    const int a0 = __builtin_popcount(f0 & 0155) & 1, b0 = __builtin_popcount(f0 & 0117) & 1;
+    const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
+#define WR_RECIP32(d) (uint32_t)((0x100000000ull + (d) - 1) / (d))
+    const uint32_t recip_tab[8] = { WR_RECIP32(24), WR_RECIP32(36), WR_RECIP32(48), WR_RECIP32(72),
+                                    WR_RECIP32(96), WR_RECIP32(144), WR_RECIP32(192), WR_RECIP32(216) };
+#undef WR_RECIP32
+    const bool idx16 = ((reinterpret_cast<uintptr_t>(idx_all) | ((size_t)max_sym * 48)) & 15) == 0;
+
+    for (uint32_t slot = wave; slot < n_slots; slot += n_waves_total) {
+        const wifirx_frame fr = frames[slot];
+        const int enc = fr.encoding & 7, psdu_len = fr.psdu_len;
+        const int n_dbps = ndbps_tab[enc];
+        const int n_sym = (16 + 8 * psdu_len + 6 + n_dbps - 1) / n_dbps;
+        const bool ok = (fr.flags & WIFIRX_F_COMPLETE) && psdu_len <= (int)psdu_stride && psdu_len <= WIFIRX_MAX_PSDU &&
+                        n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym && (uint32_t)(n_sym * n_dbps) <= n_steps_cap;
+        if (!ok) continue;                                       // wave-uniform: one frame per wave
+        const int n_data = n_sym * n_dbps;
+        const uint8_t* fidx = idx_all + (size_t)slot * max_sym * 48;
+        const uint32_t recip = recip_tab[enc];
+        const uint32_t* tab_enc = src_tab + enc * WR_DEC_TAB_STRIDE;
+
+        // ---- add-compare-select: tiles of 60 symbols, chunks of 60 trellis steps ----
+        int pm = (s == 0) ? 0 : (1 << 24);
+        for (int sym0 = 0; sym0 < n_sym; sym0 += 60) {
+            const int nsy = n_sym - sym0 < 60 ? n_sym - sym0 : 60;
+            const int nbytes = nsy * 48;
+            __builtin_amdgcn_wave_barrier();
+            if (idx16) {
+                for (int o = lane * 16; o < nbytes; o += 1024)
+                    *reinterpret_cast<uint4*>(tile + o) = *reinterpret_cast<const uint4*>(fidx + sym0 * 48 + o);
+            } else {
+                for (int o = lane; o < nbytes; o += 64) tile[o] = fidx[sym0 * 48 + o];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int t_hi = (sym0 + nsy) * n_dbps;
+            for (int t0 = sym0 * n_dbps; t0 < t_hi; t0 += WR_DEC_CHUNK) {
+                const int t = t0 + lane;
+                int ra, rb;
+                gather_step(tile, sym0, tab_enc, n_dbps, recip, t, lane < WR_DEC_CHUNK && t < t_hi, ra, rb);
+                const uint64_t A1 = __ballot(ra == 1), AV = __ballot(ra != 2);
+                const uint64_t B1 = __ballot(rb == 1), BV = __ballot(rb != 2);
+                const int jn = t_hi - t0 < WR_DEC_CHUNK ? t_hi - t0 : WR_DEC_CHUNK;
+                uint64_t mydec = 0;
+                for (int j = 0; j < jn; j++) {
+                    const int sa = (int)((A1 >> j) & 1), va = (int)((AV >> j) & 1);
+                    const int sb = (int)((B1 >> j) & 1), vb = (int)((BV >> j) & 1);
+                    const int bm0 = (va & (sa ^ a0)) + (vb & (sb ^ b0));
+                    const int bm1 = (va + vb) - bm0;
+                    const int m0 = __shfl(pm, p0, 64) + bm0;
+                    const int m1 = __shfl(pm, p1, 64) + bm1;
+                    const bool sel = m1 < m0;
+                    pm = sel ? m1 : m0;
+                    const uint64_t d = __ballot(sel);
+                    if (lane == j) mydec = d;
+                }
+                if (lane < jn) dec[t] = mydec;
+            }
+        }
+        // ---- best final state: smallest metric, lowest state on ties ----
+        int key = (pm << 6) | s;
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) {
+            int o = __shfl_xor(key, k, 64);
+            key = o < key ? o : key;
+        }
+        int st = key & 63;
+        __threadfence_block();
+        // ---- traceback, one chunk of survivor words in registers at a time; decoded bits 60 per word ----
+        const int n_chunks = (n_data + WR_DEC_CHUNK - 1) / WR_DEC_CHUNK;
+        for (int c = n_chunks - 1; c >= 0; c--) {
+            const int t = c * WR_DEC_CHUNK + lane;
+            const uint64_t dw = (lane < WR_DEC_CHUNK && t < n_data) ? dec[t] : 0;
+            const uint32_t lo = (uint32_t)dw, hi = (uint32_t)(dw >> 32);
+            const int jn = n_data - c * WR_DEC_CHUNK < WR_DEC_CHUNK ? n_data - c * WR_DEC_CHUNK : WR_DEC_CHUNK;
+            uint64_t word = 0;
+            for (int j = jn - 1; j >= 0; j--) {
+                word |= (uint64_t)(st & 1) << j;
+                const uint32_t dlo = (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
+                const uint32_t dhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, j);
+                const uint32_t h = (st < 32 ? (dlo >> st) : (dhi >> (st - 32))) & 1u;
+                st = (st >> 1) | (int)(h << 5);
+            }
+            if (lane == 0) words[c] = word;
+        }
+        __threadfence_block();
+        // ---- descramble: x^7+x^4+1, state from the first 7 decoded bits; the feedback sequence has period 127 ----
+        const uint64_t w0 = words[0];
+        int state = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) state |= (int)((w0 >> i) & 1) << (6 - i);
+        uint64_t seq_lo = 0, seq_hi = 0;             // feedback bit for decoded positions 7, 8, ...
+        for (int i = 0; i < 127; i++) {
+            const int fb = ((state >> 6) ^ (state >> 3)) & 1;
+            if (i < 64) seq_lo |= (uint64_t)fb << i; else seq_hi |= (uint64_t)fb << (i - 64);
+            state = ((state << 1) & 0x7e) | fb;
+        }
+        uint8_t* psdu = psdu_all + (size_t)slot * psdu_stride;
+        uint32_t crc = 0xffffffffu;
+        for (int b0_ = 0; b0_ < psdu_len; b0_ += 64) {
+            const int b = b0_ + lane;
+            unsigned byte = 0;
+            if (b < psdu_len) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = 16 + 8 * b + k;
+                    const int q = (i - 7) % 127;
+                    const unsigned fb = (unsigned)(((q < 64 ? (seq_lo >> q) : (seq_hi >> (q - 64)))) & 1);
+                    const int wi = i / WR_DEC_CHUNK, wb = i - wi * WR_DEC_CHUNK;
+                    const unsigned d = (unsigned)((words[wi] >> wb) & 1);
+                    byte |= (d ^ fb) << k;
+                }
+                psdu[b] = (uint8_t)byte;
+            }
+            // CRC-32 over the PSDU incl. FCS (residue 0x2144DF1C): the 64 bytes of this pass in order
+            const int jn = psdu_len - b0_ < 64 ? psdu_len - b0_ : 64;
+            for (int j = 0; j < jn; j++) crc = crc32_update(crc, (uint32_t)__builtin_amdgcn_readlane((int)byte, j));
+        }
+        crc = ~crc;
+        if (lane == 0) {
+            uint32_t fl = fr.flags | WIFIRX_F_DECODED;
+            if (psdu_len >= 4 && crc == 558161692u) fl |= WIFIRX_F_CRC_OK; else fl &= ~WIFIRX_F_CRC_OK;
+            frames[slot].flags = fl;
+        }
+    }
+}
+
 // longest trellis (in steps) among the frames decode_kernel would accept
 __global__ __launch_bounds__(256)
 void decode_maxsteps_kernel(uint32_t n_slots, uint32_t max_sym, const wifirx_frame* __restrict__ frames,
@@ -491,5 +651,15 @@ extern "C" hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_
     uint32_t blocks = (n_waves + 3) / 4;
     hipLaunchKernelGGL(wr::decode_kernel, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, idx, psdu,
                        psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t wr_launch_decode_small(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
+                                             const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
+                                             size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves)
+{
+    if (n_slots == 0 || n_waves == 0) return hipSuccess;
+    hipLaunchKernelGGL(wr::decode_small_kernel, dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, frames, idx, psdu,
+                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves);
     return hipGetLastError();
 }

@@ -11,6 +11,7 @@
 #endif
 #define WR_STREAM_SPAN     16       // tiles of 64 samples one wave scans in stream-mode detection
 #define WR_DECODE_MAX_WAVES 4096    // waves of the decode kernel (grid-stride; each owns a scratch slice)
+#define WR_DECODE_SMALL_MAX 16384      // batches up to this many frames take the wave-per-frame decode kernel
 #define WR_DECODE_FRAMES_PER_WAVE 128   // two frames per lane: packed 16-bit path metrics
 #define WR_DECODE_SCRATCH_BUDGET (16ull << 30)   // bytes of survivor scratch a decode call may hold
 
@@ -49,6 +50,9 @@ hipError_t wr_launch_decode_maxsteps(hipStream_t st, uint32_t n_slots, uint32_t 
 hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                             const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
                             size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave);
+hipError_t wr_launch_decode_small(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
+                                  const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
+                                  size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves);
 hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_samp, int64_t tile0,
                                    int64_t n_tiles, float thr, uint64_t* masks, float2* A);
 hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,

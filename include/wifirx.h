@@ -114,6 +114,10 @@ typedef struct wifirx_config {
  * decodes them in one go (0 = on every push).  A GNU Radio scheduler hands work() a few thousand items at a
  * time; one GPU round trip per such call would not keep up with the sample rate.  A push with n = 0 flushes. */
 #define WIFIRX_P_STREAM_BATCH 5
+/* decode_mac has two kernels with identical results: 128 frames per wave (throughput; a lone wave needs ~4 ms)
+ * and one frame per wave (latency; ~0.2 ms per frame).  Batches of up to this many frames take the second one
+ * (default 16384; 0 = always the first). */
+#define WIFIRX_P_DECODE_SMALL_MAX 6
 
 typedef struct wifirx_handle wifirx_handle;
 

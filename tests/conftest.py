@@ -29,3 +29,12 @@ def gpu_available():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+@pytest.fixture(params=["wave_per_frame", "frames_per_lane"])
+def decode_path(request, monkeypatch):
+    """decode_mac has a latency kernel (one wave per frame, small batches) and a throughput kernel (128 frames per
+    wave); both must give the oracle's bytes.  Tests that name this fixture run once with each (the library reads
+    WIFIRX_DECODE_SMALL_MAX when a handle is created)."""
+    monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "1000000000" if request.param == "wave_per_frame" else "0")
+    return request.param

@@ -69,7 +69,7 @@ def test_comb_and_sta_track_a_drifting_channel(orc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("chan_est", [2, 3])
 @pytest.mark.parametrize("encoding", range(8))
-def test_gpu_bit_exact(orc, chan_est, encoding):
+def test_gpu_bit_exact(orc, chan_est, encoding, decode_path):
     from wifirx import capi
     iq, slot_len, tx = make_slots(24, encoding, snr_db=24.0, seed=100 + encoding, taps=TAPS if encoding % 2 else None)
     rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=6, want_carrier=True, chan_est=chan_est)

@@ -9,7 +9,7 @@ CASES = {c[0]: c for c in edge_cases()}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_edge_case_bit_exact(orc, name):
+def test_edge_case_bit_exact(orc, name, decode_path):
     from wifirx import capi
     _, iq, slot_len, max_sym, exp = CASES[name]
     rx = capi.WifiRx(max_sym=max_sym, llr_bits=6, want_carrier=True)
@@ -76,7 +76,7 @@ def test_full_size_properties():
     rx.free_out(dev); rx.free_out(dev2); slots.free(); rx.close()
 
 
-def test_decode_with_unaligned_buffers(orc):
+def test_decode_with_unaligned_buffers(orc, decode_path):
     """decode_mac's fast paths (16-byte tile copies of the decisions, dword PSDU stores) are taken only when the
     caller's buffers allow it: an odd PSDU stride and a decisions buffer that is merely 4-byte aligned must give
     the same bytes"""

@@ -43,7 +43,7 @@ CASES = dict(_cases())
 
 @pytest.mark.parametrize("name", sorted(CASES))
 @pytest.mark.parametrize("chan_est", [0, 1])
-def test_fuzz_bit_exact(orc, name, chan_est):
+def test_fuzz_bit_exact(orc, name, chan_est, decode_path):
     from wifirx import capi
     iq = np.ascontiguousarray(CASES[name]).reshape(-1)
     L = CASES[name].shape[1]

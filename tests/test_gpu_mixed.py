@@ -29,7 +29,7 @@ def mixed_batch(n=150, slot_len=3200, seed=5):
     return iq.reshape(-1), slot_len, meta
 
 
-def test_mixed_rates_in_one_batch(orc):
+def test_mixed_rates_in_one_batch(orc, decode_path):
     from wifirx import capi
     iq, slot_len, meta = mixed_batch()
     max_sym = 140

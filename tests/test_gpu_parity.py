@@ -41,7 +41,7 @@ def test_batch_bit_exact_all_rates(capi, orc, encoding):
 
 @pytest.mark.parametrize("encoding,snr", [(0, 25), (1, 25), (2, 25), (3, 25), (4, 25), (5, 25), (6, 28), (7, 28),
                                           (2, 4.0), (5, 14.0), (7, 19.0)])
-def test_decode_mac_bit_exact(capi, orc, encoding, snr):
+def test_decode_mac_bit_exact(capi, orc, encoding, snr, decode_path):
     """decode_mac (Viterbi, descramble, CRC) on the device == oracle, also where the channel
     leaves bit errors (survivor tie-breaks must agree)."""
     iq, slot_len, tx = make_slots(40, encoding, snr_db=snr, seed=100 + encoding)

@@ -37,7 +37,7 @@ def oracle_stream(orc, x, max_sym=511):
 
 @pytest.mark.parametrize("chunk,batch", [(777, 0), (4096, 0), (100000, 0), (10**7, 0), (777, 20000), (4096, 1 << 20)])
 @pytest.mark.parametrize("noise", [True, False])
-def test_push_poll_matches_oracle_stream(orc, chunk, batch, noise):
+def test_push_poll_matches_oracle_stream(orc, chunk, batch, noise, decode_path):
     """chunk = samples per push; batch = WIFIRX_P_STREAM_BATCH (0: process every push; otherwise pushes only collect
     until that many samples wait): the frames that come out do not depend on either"""
     from wifirx import capi
