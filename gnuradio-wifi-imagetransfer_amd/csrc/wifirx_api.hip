@@ -49,6 +49,7 @@ struct wifirx_handle {
     // decode workspace
     void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;
     void*  dec_max = nullptr;       size_t dec_max_bytes = 0;
+    void*  dec_masks = nullptr;     size_t dec_masks_bytes = 0;   // decode_mac: gathered coded-bit masks of a batch
     void*  s_pack = nullptr;        size_t s_pack_bytes = 0;      // stream outputs, rows cut to their filled width
     void*  s_host = nullptr;        size_t s_host_bytes = 0;      // pinned landing zone of the packed outputs
 
@@ -172,6 +173,7 @@ int wifirx_destroy(wifirx_handle* h)
                      h->s_car, h->s_psdu };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->s_pack) (void)hipFree(h->s_pack);
+    if (h->dec_masks) (void)hipFree(h->dec_masks);
     if (h->s_host) (void)hipHostFree(h->s_host);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

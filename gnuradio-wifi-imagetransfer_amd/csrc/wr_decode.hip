@@ -15,9 +15,9 @@
 // stay far below 2^15 and the signed difference orders them; decisions depend on differences only.
 // Traceback, descrambling and the CRC run per lane, for its two frames.
 //
-// The received coded bits are gathered beforehand by the whole wave for one frame at a time
-// (lane <-> trellis step: de-puncture + de-interleave + bit extraction from the hard decisions) into
-// per-frame bit masks that go through LDS to the lane that owns the frame.
+// The received coded bits are gathered beforehand by decode_gather_kernel (one wave per frame, lane <-> trellis
+// step: de-puncture + de-interleave + bit extraction from the hard decisions) into per-frame bit masks in global
+// memory, which reach the lane that owns the frame through LDS, one 60-step chunk at a time.
 //
 // Results are bit-identical to the oracle's viterbi_decode(): same metrics (Hamming, erasures free),
 // same tie rule (the survivor with older bit 0 wins), same final state rule (smallest metric, lowest
@@ -107,6 +107,82 @@ __device__ __forceinline__ void gather_step(const uint8_t* tile, int sym0, const
         const uint8_t* sp = tile + (sym - sym0) * 48;
         if (!(ea & WR_SRC_PUNCT)) ra = (sp[ea & 63u] >> (ea >> 6)) & 1;
         if (!(eb & WR_SRC_PUNCT)) rb = (sp[eb & 63u] >> (eb >> 6)) & 1;
+    }
+}
+
+// trellis steps of a frame decode_mac accepts (a multiple of 12), 0 for a frame it leaves alone
+__device__ __forceinline__ int frame_steps(uint32_t flags, int enc, int len, uint32_t psdu_stride, uint32_t max_sym,
+                                           uint32_t n_steps_cap)
+{
+    const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
+    const int n_dbps = ndbps_tab[enc & 7];
+    const int n_sym = (16 + 8 * len + 6 + n_dbps - 1) / n_dbps;
+    const bool ok = (flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride && len <= WIFIRX_MAX_PSDU &&
+                    n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym && (uint32_t)(n_sym * n_dbps) <= n_steps_cap;
+    return ok ? n_sym * n_dbps : 0;
+}
+
+#define WR_RECIP32(d) (uint32_t)((0x100000000ull + (d) - 1) / (d))      /* ceil(2^32 / d) */
+
+// ---- gather kernel: the received coded bits of every frame as 60-step bit masks, one wave per frame with lane <->
+//      trellis step.  The decisions of a frame come in tiles of 60 OFDM symbols (a whole number of chunks at every
+//      rate), copied into the wave's LDS by coalesced 16-byte loads.  Output layout: for decode task T (the
+//      frames_per_wave frames one wave of decode_kernel handles) [chunk][A1,AV,B1,BV][frame position 0..127]. ----
+__global__ __launch_bounds__(256)
+void decode_gather_kernel(uint32_t n_slots, uint32_t max_sym, const wifirx_frame* __restrict__ frames,
+                          const uint8_t* __restrict__ idx_all, uint32_t psdu_stride, uint64_t* __restrict__ masks_all,
+                          uint32_t n_steps_cap, uint32_t frames_per_wave)
+{
+    __shared__ uint8_t tile_all[4][60 * 48];
+    __shared__ uint32_t src_tab[8 * WR_DEC_TAB_STRIDE];
+    build_src_table(src_tab);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    uint8_t* tile = tile_all[wv];
+    const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
+    const uint32_t recip_tab[8] = { WR_RECIP32(24), WR_RECIP32(36), WR_RECIP32(48), WR_RECIP32(72),
+                                    WR_RECIP32(96), WR_RECIP32(144), WR_RECIP32(192), WR_RECIP32(216) };
+    const bool idx16 = ((reinterpret_cast<uintptr_t>(idx_all) | ((size_t)max_sym * 48)) & 15) == 0;
+    const uint32_t fA = frames_per_wave < 64 ? frames_per_wave : 64;
+    const size_t task_words = ((size_t)n_steps_cap / WR_DEC_CHUNK + 2) * 4 * WR_DECODE_FRAMES_PER_WAVE;
+    for (uint32_t slot = blockIdx.x * 4 + wv; slot < n_slots; slot += gridDim.x * 4) {
+        const wifirx_frame fr = frames[slot];
+        const int f_enc = fr.encoding & 7;
+        const int f_ndata = frame_steps(fr.flags, f_enc, fr.psdu_len, psdu_stride, max_sym, n_steps_cap);
+        if (f_ndata == 0) continue;
+        const uint32_t task = slot / frames_per_wave, rr = slot - task * frames_per_wave;
+        const uint32_t f = rr < fA ? rr : 64 + (rr - fA);           // position in the decode wave: lane f & 63, half f >> 6
+        uint64_t* masks = masks_all + (size_t)task * task_words;
+        const uint8_t* fidx = idx_all + (size_t)slot * max_sym * 48;
+        const int f_ndbps = ndbps_tab[f_enc];
+        const uint32_t f_recip = recip_tab[f_enc];
+        const int f_nsym = f_ndata / f_ndbps;
+        for (int sym0 = 0; sym0 < f_nsym; sym0 += 60) {
+            const int nsy = f_nsym - sym0 < 60 ? f_nsym - sym0 : 60;
+            const int nbytes = nsy * 48;
+            __builtin_amdgcn_wave_barrier();
+            if (idx16) {
+                for (int o = lane * 16; o < nbytes; o += 1024)
+                    *reinterpret_cast<uint4*>(tile + o) = *reinterpret_cast<const uint4*>(fidx + sym0 * 48 + o);
+            } else {
+                for (int o = lane; o < nbytes; o += 64) tile[o] = fidx[sym0 * 48 + o];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int t_hi = (sym0 + nsy) * f_ndbps;
+            for (int c = sym0 * f_ndbps / WR_DEC_CHUNK; c * WR_DEC_CHUNK < t_hi; c++) {
+                const int t = c * WR_DEC_CHUNK + lane;
+                int ra, rb;
+                gather_step(tile, sym0, src_tab + f_enc * WR_DEC_TAB_STRIDE, f_ndbps, f_recip, t,
+                            lane < WR_DEC_CHUNK && t < t_hi, ra, rb);
+                const uint64_t A1 = __ballot(ra == 1), AV = __ballot(ra != 2);
+                const uint64_t B1 = __ballot(rb == 1), BV = __ballot(rb != 2);
+                if (lane < 4) {
+                    uint64_t wsel = lane == 0 ? A1 : lane == 1 ? AV : lane == 2 ? B1 : BV;
+                    masks[((size_t)c * 4 + lane) * WR_DECODE_FRAMES_PER_WAVE + f] = wsel;
+                }
+            }
+        }
     }
 }
 
@@ -206,12 +282,9 @@ __global__ __launch_bounds__(256, WR_DEC_WAVES_PER_SIMD)
 void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
                    const uint8_t* __restrict__ idx_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
                    uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total,
-                   uint32_t frames_per_wave)
+                   uint32_t frames_per_wave, const uint64_t* __restrict__ masks_all)
 {
     __shared__ uint64_t lds_all[4][WR_DEC_LDS_WORDS];
-    __shared__ uint32_t src_tab[8 * WR_DEC_TAB_STRIDE];
-    build_src_table(src_tab);
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * 4 + wv;
@@ -220,52 +293,26 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
     const size_t n_data_cap = n_steps_cap;               // trellis steps the scratch slice of a wave holds
     uint32_t* surv = reinterpret_cast<uint32_t*>(scratch + (size_t)wave * scratch_stride);   // [step][lane][4 pieces]
     uint32_t* dbits = surv + n_data_cap * 256;                                               // [word][A/B][lane]
-    uint64_t* masks_base = reinterpret_cast<uint64_t*>(dbits + (n_data_cap / 32 + 2) * WR_DECODE_FRAMES_PER_WAVE);   // 2 x [chunk][4][frame]
     const uint32_t k15 = 0x000f000fu, k2 = 0x00020002u, k1 = 0x00010001u;
 
-    const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
-#define WR_RECIP32(d) (uint32_t)((0x100000000ull + (d) - 1) / (d))      /* ceil(2^32 / d) */
-    const uint32_t recip_tab[8] = { WR_RECIP32(24), WR_RECIP32(36), WR_RECIP32(48), WR_RECIP32(72),
-                                    WR_RECIP32(96), WR_RECIP32(144), WR_RECIP32(192), WR_RECIP32(216) };
-#undef WR_RECIP32
-
-    // A wave's tasks (128 frames each, grid-stride).  The gather and the traceback/CRC phases wait on memory, the
-    // add-compare-select phase keeps the vector ALU busy; waves that walk their phases in step leave the ALU idle
-    // while all of them wait.  So the workgroups alternate between two orders: even ones gather a task right before
-    // decoding it (G0 R0 G1 R1 ...), odd ones keep the gather one task ahead (G0 G1 R0 G2 R1 ...), with two mask
-    // buffers -- the waves that share a SIMD come from different workgroups and now overlap their phases.
-    // frames_per_wave <= 128: a small batch is spread over more waves (fewer frames each: the gather is per frame and
-    // the butterflies cost the same whatever the number of active lanes, so this only shortens the latency).
-    // Lane l owns frames base + l (l < fA) and base + fA + l (l < fB).
+    // A wave's tasks (frames_per_wave <= 128 frames each, grid-stride); lane l owns frames base + l (l < fA) and
+    // base + fA + l (l < fB).  The coded-bit masks of every task were written by decode_gather_kernel.
     const uint32_t fA = frames_per_wave < 64 ? frames_per_wave : 64, fB = frames_per_wave - fA;
-    const uint32_t task_stride = n_waves_total * frames_per_wave;
-    const uint32_t first = wave * frames_per_wave;
-    const int n_tasks = first < n_slots ? (int)((n_slots - first + task_stride - 1) / task_stride) : 0;
-    const int lead = ((blockIdx.x >> 8) & 1) ? 2 : 1;      // workgroups i, i + 256, ... tend to share a CU
-    const size_t masks_words = ((size_t)n_data_cap / WR_DEC_CHUNK + 2) * 4 * WR_DECODE_FRAMES_PER_WAVE;
-    for (int gi = 0, ri = 0; ri < n_tasks;) {
-        const bool do_gather = gi < n_tasks && gi - ri < lead;
-        const int task = do_gather ? gi : ri;
-        const uint32_t base = first + (uint32_t)task * task_stride;
-        uint64_t* masks = masks_base + (size_t)(task & 1) * masks_words;
-        if (do_gather) gi++; else ri++;
+    const size_t task_words = ((size_t)n_data_cap / WR_DEC_CHUNK + 2) * 4 * WR_DECODE_FRAMES_PER_WAVE;
+    const uint32_t n_tasks = (n_slots + frames_per_wave - 1) / frames_per_wave;
+    for (uint32_t task = wave; task < n_tasks; task += n_waves_total) {
+        const uint32_t base = task * frames_per_wave;
+        const uint64_t* masks = masks_all + (size_t)task * task_words;
         // ---- my two frames ----
-        int enc[2], n_data[2];
+        int n_data[2];
         int n_max = 0;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t slot = base + (h ? fA : 0u) + lane;
-            const bool mine = (uint32_t)lane < (h ? fB : fA) && slot < n_slots;
-            uint32_t flags = 0;
-            int len = 0;
-            enc[h] = 0;
-            if (mine) { flags = frames[slot].flags; enc[h] = frames[slot].encoding & 7; len = frames[slot].psdu_len; }
-            const int n_dbps = ndbps_tab[enc[h]];
-            const int n_sym = (16 + 8 * len + 6 + n_dbps - 1) / n_dbps;
-            const bool ok = mine && (flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride &&
-                            len <= WIFIRX_MAX_PSDU && n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym &&
-                            (uint32_t)(n_sym * n_dbps) <= n_steps_cap;
-            n_data[h] = ok ? n_sym * n_dbps : 0;                // multiple of 12; 0: nothing to decode
+            n_data[h] = 0;
+            if ((uint32_t)lane < (h ? fB : fA) && slot < n_slots)
+                n_data[h] = frame_steps(frames[slot].flags, frames[slot].encoding, frames[slot].psdu_len, psdu_stride, max_sym,
+                                        n_steps_cap);
             n_max = n_data[h] > n_max ? n_data[h] : n_max;
         }
 #pragma unroll
@@ -274,54 +321,6 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
             n_max = o > n_max ? o : n_max;
         }
         if (n_max == 0) continue;
-        const uint64_t valid_mask[2] = { __ballot(n_data[0] > 0), __ballot(n_data[1] > 0) };
-        if (do_gather) {
-
-        // ---- phase 1: gather the received coded bits of every frame, one frame at a time, lane <-> step, into the
-        //      wave's mask area [chunk][A1,AV,B1,BV][frame] (global scratch; nothing else is live in registers here).
-        //      The decisions of a frame come in tiles of 60 OFDM symbols, copied into the wave's LDS by coalesced
-        //      16-byte loads: one global round trip per tile instead of one per chunk (60 symbols hold a whole
-        //      number of 60-step chunks at every rate) ----
-        uint8_t* tile = reinterpret_cast<uint8_t*>(lds);
-        const bool idx16 = ((reinterpret_cast<uintptr_t>(idx_all) | ((size_t)max_sym * 48)) & 15) == 0;
-        for (int f = 0; f < WR_DECODE_FRAMES_PER_WAVE; f++) {
-            const int fh = f >> 6, fl = f & 63;
-            if (!((valid_mask[fh] >> fl) & 1)) continue;
-            const int f_enc = __builtin_amdgcn_readlane(fh ? enc[1] : enc[0], fl);
-            const int f_ndata = __builtin_amdgcn_readlane(fh ? n_data[1] : n_data[0], fl);
-            const uint8_t* fidx = idx_all + (size_t)(base + (fh ? fA : 0u) + fl) * max_sym * 48;
-            const int f_ndbps = ndbps_tab[f_enc];
-            const uint32_t f_recip = recip_tab[f_enc];
-            const int f_nsym = f_ndata / f_ndbps;
-            for (int sym0 = 0; sym0 < f_nsym; sym0 += 60) {
-                const int nsy = f_nsym - sym0 < 60 ? f_nsym - sym0 : 60;
-                const int nbytes = nsy * 48;
-                __builtin_amdgcn_wave_barrier();
-                if (idx16) {
-                    for (int o = lane * 16; o < nbytes; o += 1024)
-                        *reinterpret_cast<uint4*>(tile + o) = *reinterpret_cast<const uint4*>(fidx + sym0 * 48 + o);
-                } else {
-                    for (int o = lane; o < nbytes; o += 64) tile[o] = fidx[sym0 * 48 + o];
-                }
-                __builtin_amdgcn_wave_barrier();
-                const int t_hi = (sym0 + nsy) * f_ndbps;
-                for (int c = sym0 * f_ndbps / WR_DEC_CHUNK; c * WR_DEC_CHUNK < t_hi; c++) {
-                    const int t = c * WR_DEC_CHUNK + lane;
-                    int ra, rb;
-                    gather_step(tile, sym0, src_tab + f_enc * WR_DEC_TAB_STRIDE, f_ndbps, f_recip, t,
-                                lane < WR_DEC_CHUNK && t < t_hi, ra, rb);
-                    const uint64_t A1 = __ballot(ra == 1), AV = __ballot(ra != 2);
-                    const uint64_t B1 = __ballot(rb == 1), BV = __ballot(rb != 2);
-                    if (lane < 4) {
-                        uint64_t wsel = lane == 0 ? A1 : lane == 1 ? AV : lane == 2 ? B1 : BV;
-                        masks[((size_t)c * 4 + lane) * WR_DECODE_FRAMES_PER_WAVE + f] = wsel;
-                    }
-                }
-            }
-        }
-        __threadfence_block();
-        continue;
-        }
 
         // ---- phase 2: add-compare-select ----
         uint32_t pm[64];
@@ -645,12 +644,18 @@ extern "C" hipError_t wr_launch_decode_maxsteps(hipStream_t st, uint32_t n_slots
 
 extern "C" hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                                        const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
-                                       size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave)
+                                       size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
+                                       uint64_t* masks)
 {
     if (n_slots == 0 || n_waves == 0) return hipSuccess;
+    // the coded-bit masks of all frames first (one wave per frame, as many as fit), then the decoder proper
+    uint32_t gblocks = (n_slots + 3) / 4;
+    if (gblocks > 16384) gblocks = 16384;
+    hipLaunchKernelGGL(wr::decode_gather_kernel, dim3(gblocks), dim3(256), 0, st, n_slots, max_sym, frames, idx, psdu_stride,
+                       masks, n_steps_cap, frames_per_wave);
     uint32_t blocks = (n_waves + 3) / 4;
     hipLaunchKernelGGL(wr::decode_kernel, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, idx, psdu,
-                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave);
+                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, masks);
     return hipGetLastError();
 }
 

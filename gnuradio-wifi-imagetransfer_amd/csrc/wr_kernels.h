@@ -49,7 +49,8 @@ hipError_t wr_launch_decode_maxsteps(hipStream_t st, uint32_t n_slots, uint32_t 
                                      const wifirx_frame* frames, uint32_t psdu_stride, uint32_t* out);
 hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                             const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
-                            size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave);
+                            size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
+                            uint64_t* masks);
 hipError_t wr_launch_decode_small(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                                   const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
                                   size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves);
