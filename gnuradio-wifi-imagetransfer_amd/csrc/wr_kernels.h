@@ -5,7 +5,9 @@
 
 #include "wifirx.h"
 
-#define WR_WAVES_PER_BLOCK 4
+#ifndef WR_WAVES_PER_BLOCK
+#define WR_WAVES_PER_BLOCK 1       // demod kernels: one wave per workgroup (nothing is shared; 0.7 % faster than four)
+#endif
 #ifndef WR_DEMOD_WAVES_PER_SIMD
 #define WR_DEMOD_WAVES_PER_SIMD 4       // register budget of the demod kernels: 512/4 = 128 VGPRs
 #endif
