@@ -3,7 +3,10 @@
 in rate, length, SNR, CFO, lead-in and channel (flat / multipath), for every equaliser.  The pytest parity cases
 are hand-picked and small; this is the bulk check behind them.  Prints one JSON line.
 
-    python tools/parity_campaign.py [n_frames=20000] [seed=1]
+    python tools/parity_campaign.py [n_frames=20000] [seed=1] [long]
+
+`long`: slots of 45056 samples, PSDUs up to 1530 bytes at every rate (up to 511 OFDM symbols: the longest frames
+decode_mac accepts, and the renormalisation of its 16-bit path metrics over 12 000+ trellis steps).
 """
 import json
 import os
@@ -18,7 +21,7 @@ sys.path.insert(0, ROOT)
 from wifirx import capi, txgen  # noqa: E402
 
 
-def make_batch(n, slot_len, seed):
+def make_batch(n, slot_len, seed, max_len=1200):
     rng = np.random.default_rng(seed)
     taps_set = np.load(os.path.join(ROOT, "tests", "golden", "sv_taps.npy"))
     iq = np.zeros((n, slot_len), np.complex64)
@@ -27,7 +30,7 @@ def make_batch(n, slot_len, seed):
     while k < n:
         g = int(min(n - k, rng.integers(8, 64)))
         enc = int(rng.integers(0, 8))
-        plen = int(rng.integers(30, 1200))
+        plen = int(rng.integers(30, max_len))
         while txgen.n_sym_for(plen, enc) * 80 + 400 + 260 > slot_len:
             plen = max(30, plen // 2)
         psdu = txgen.make_psdus(g, plen, seed=seed * 100003 + k)
@@ -45,10 +48,11 @@ def make_batch(n, slot_len, seed):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    slot_len, max_sym, llr_bits = 8192, 96, 6
+    long_frames = len(sys.argv) > 3 and sys.argv[3] == "long"
+    slot_len, max_sym, llr_bits = (45056, 511, 1) if long_frames else (8192, 96, 6)
     from oracle import oracle as orc
     t0 = time.perf_counter()
-    iq = make_batch(n, slot_len, seed)
+    iq = make_batch(n, slot_len, seed, 1531 if long_frames else 1200)
     res = {"frames": n, "slot_len": slot_len, "seed": seed, "generate_s": time.perf_counter() - t0, "equalisers": {}}
     threads = os.cpu_count() or 1
     for ce, name in enumerate(("LS", "LMS", "COMB", "STA")):
