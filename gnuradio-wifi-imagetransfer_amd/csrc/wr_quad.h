@@ -217,7 +217,7 @@ __device__ __forceinline__ bool preamble_sync(const float2* __restrict__ x, long
             c32 first = oi > ok ? top_val[k] : top_val[i];
             c32 second = oi > ok ? top_val[i] : top_val[k];
             int diff = oi > ok ? oi - ok : ok - oi;
-            if (diff == 64 || diff == 63 || diff == 65) {
+            if ((diff == 64 || diff == 63 || diff == 65) && oi >= 0 && ok >= 0) {      // -1: fewer than four valid lags
                 float pr = fma_(first.im, second.im, first.re * second.re);
                 float pi = fma_(first.im, second.re, -(first.re * second.im));
                 fs = oi < ok ? oi : ok;

@@ -627,7 +627,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
         for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) {
             int used = 0;
             for (int q = 0; q < r; q++) used |= (top[q] == i);
-            if (used) continue;
+            if (used || !(mag[i] >= 0.0f)) continue;            /* a NaN magnitude is never a peak */
             if (best < 0 || mag[i] > mag[best]) best = i;
         }
         top[r] = best;
@@ -637,6 +637,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     for (int i = 0; i < 3 && found != 64; i++) {
         for (int k = i + 1; k < 4; k++) {
             int oi = top[i], ok = top[k];
+            if (oi < 0 || ok < 0) continue;                     /* fewer than four valid lags */
             c32 first = oi > ok ? corr[ok] : corr[oi];
             c32 second = oi > ok ? corr[oi] : corr[ok];
             int diff = abs(oi - ok);
