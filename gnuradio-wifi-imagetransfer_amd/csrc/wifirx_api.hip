@@ -61,6 +61,7 @@ struct wifirx_handle {
     int64_t  last_trig = -(1ll << 40);
     int64_t  stream_batch = 0;      // WIFIRX_P_STREAM_BATCH
     uint32_t decode_small_max = WR_DECODE_SMALL_MAX;   // WIFIRX_P_DECODE_SMALL_MAX
+    int32_t  llr_csi = 0;           // WIFIRX_P_LLR_CSI
     int64_t  sprocessed = 0;        // absolute index up to which pushes have been processed
     uint8_t* s_above = nullptr;     float2* s_A = nullptr;    int64_t s_above_cap = 0;
     std::vector<PendingTrig> pending;
@@ -118,7 +119,7 @@ wr::DemodParams params_of(const wifirx_handle* h)
     p.max_sym = h->cfg.max_sym;
     p.llr_bits = h->cfg.llr_bits;
     p.chan_est = h->cfg.chan_est;
-    p.pad_ = 0;
+    p.llr_csi = h->llr_csi;
     return p;
 }
 
@@ -199,6 +200,9 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
         if ((int)value < WIFIRX_EQ_LS || (int)value > WIFIRX_EQ_STA)
             return fail(h, WIFIRX_EINVAL, "chan_est must be one of WIFIRX_EQ_LS, LMS, COMB, STA");
         h->cfg.chan_est = (int)value;
+        return WIFIRX_OK;
+    case WIFIRX_P_LLR_CSI:
+        h->llr_csi = value != 0;
         return WIFIRX_OK;
     case WIFIRX_P_DECODE_SMALL_MAX:
         if (!(value >= 0) || value > 4e9) return fail(h, WIFIRX_EINVAL, "decode threshold out of range");

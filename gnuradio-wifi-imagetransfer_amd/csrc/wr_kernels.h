@@ -27,7 +27,7 @@ struct DemodParams {
     uint32_t max_sym;
     uint32_t llr_bits;
     int32_t  chan_est;      // WIFIRX_EQ_LS / WIFIRX_EQ_LMS
-    int32_t  pad_;
+    int32_t  llr_csi;       // 1: LLRs weighted by |H|^2 (WIFIRX_P_LLR_CSI)
 };
 
 // one detected frame of a continuous stream (stream mode)

@@ -24,7 +24,8 @@ namespace wr {
 #define WR_QLDS_H       (WR_QLDS_SCRATCH)            // 4 x 64 float2: channel estimate, lane-private slots
 #define WR_QLDS_TW      (WR_QLDS_H + 512)              // 6 x 16 float2: stage-1/2 twiddles by row lane
 #define WR_QLDS_PREV    (WR_QLDS_TW + 192)             // 4 rows x 4 float2: pilots of the previous symbol
-#define WR_QLDS_FLOATS  (WR_QLDS_PREV + 32)          // per wave: max(383 preamble samples, 4 rows x 64 values) complex
+#define WR_QLDS_W       (WR_QLDS_PREV + 32)            // 4 x 64 floats: |H|^2 of the LS estimate (LLR weight, lane-private slots)
+#define WR_QLDS_FLOATS  (WR_QLDS_W + 256)            // per wave: max(383 preamble samples, 4 rows x 64 values) complex
 #define WR_QLDS_DH      (WR_QLDS_FLOATS)             // COMB only: 4 x 64 float2, the running estimate d_H
 #define WR_QLDS_FLOATS_EQ(EQ) (WR_QLDS_FLOATS + ((EQ) == WIFIRX_EQ_COMB ? 512 : 0))
 
@@ -281,10 +282,12 @@ __device__ __forceinline__ float row_xor_sum16(float v)
 
 // a6 + a7 stores of one lane's four bins for constellation NB (compile-time: no per-lane branching on it).
 // ok = row active; the pointers are the row's output slices.
-template <int NB>
+// CSI: every LLR is multiplied by w[j] = |H|^2 of its sub-carrier (spec rule 13).
+template <int NB, bool CSI>
 __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrier)[4], bool ok, int q,
                                            uint8_t* __restrict__ idx, float2* __restrict__ car,
-                                           float* __restrict__ llr, bool has_idx, bool has_car, bool want_llr)
+                                           float* __restrict__ llr, bool has_idx, bool has_car, bool want_llr,
+                                           const float (&w)[4])
 {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -295,18 +298,21 @@ __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrie
         if (want_llr) {
             const float are = __builtin_fabsf(Y[j].re), aim = __builtin_fabsf(Y[j].im);
             float* lp = llr + (size_t)o * NB;
+            const float wj = CSI ? w[j] : 1.0f;
+#define WR_WT(v) (CSI ? (v) * wj : (v))
             if (NB == 1) {
-                lp[0] = Y[j].re;
+                lp[0] = WR_WT(Y[j].re);
             } else if (NB == 2) {
-                *reinterpret_cast<float2*>(lp) = make_float2(Y[j].re, Y[j].im);
+                *reinterpret_cast<float2*>(lp) = make_float2(WR_WT(Y[j].re), WR_WT(Y[j].im));
             } else if (NB == 4) {
-                *reinterpret_cast<float4*>(lp) = make_float4(Y[j].re, WR_T16_2 - are, Y[j].im, WR_T16_2 - aim);
+                *reinterpret_cast<float4*>(lp) = make_float4(WR_WT(Y[j].re), WR_WT(WR_T16_2 - are), WR_WT(Y[j].im), WR_WT(WR_T16_2 - aim));
             } else {
                 float2* l2 = reinterpret_cast<float2*>(lp);
-                l2[0] = make_float2(Y[j].re, WR_T64_4 - are);
-                l2[1] = make_float2(WR_T64_2 - __builtin_fabsf(are - WR_T64_4), Y[j].im);
-                l2[2] = make_float2(WR_T64_4 - aim, WR_T64_2 - __builtin_fabsf(aim - WR_T64_4));
+                l2[0] = make_float2(WR_WT(Y[j].re), WR_WT(WR_T64_4 - are));
+                l2[1] = make_float2(WR_WT(WR_T64_2 - __builtin_fabsf(are - WR_T64_4)), WR_WT(Y[j].im));
+                l2[2] = make_float2(WR_WT(WR_T64_4 - aim), WR_WT(WR_T64_2 - __builtin_fabsf(aim - WR_T64_4)));
             }
+#undef WR_WT
         }
     }
 }
@@ -406,6 +412,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     }
     float2* Hl = reinterpret_cast<float2*>(qlds + WR_QLDS_H) + lane;      // element j at Hl[64 j]
     float2* pvl = reinterpret_cast<float2*>(qlds + WR_QLDS_PREV) + 4 * row;
+    float* Wl = qlds + WR_QLDS_W + lane;                                  // element j at Wl[64 j]
     float2* DHl = reinterpret_cast<float2*>(qlds + (COMB ? WR_QLDS_DH : WR_QLDS_H)) + lane;   // COMB: d_H; else = Hl
     float cw[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, cu[4] = { 0.0f, 0.0f, 0.0f, 0.0f };           // COMB: interpolation weights
     if (COMB) {
@@ -607,6 +614,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 sv[j] = usedj ? fma_(u.im, u.im, u.re * u.re) : 0.0f;
                 float g = 0.5f * WR_LTS_FREQ[i];
                 const float hr = u.re * g, hi = u.im * g;
+                const float dd = fma_(hi, hi, hr * hr);             // |H|^2: LS equaliser's divisor, LLR weight
+                if (prm.llr_csi) Wl[64 * j] = usedj ? dd : 0.0f;
                 if (csi_all && usedj && act) csi_all[(size_t)out * 52 + (i - 6 - (i > 32))] = make_float2(hr, hi);
                 if (LMS || STA) {
                     Hl[64 * j] = usedj ? make_float2(hr, hi) : make_float2(1.0f, 0.0f);
@@ -614,7 +623,6 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                     // COMB equalises with d_H (own LDS area); the LS estimate only feeds the SNR figure and the CSI
                 } else {
                     // G = conj(H)/|H|^2 replaces H in LDS: the one-tap equaliser as a multiplier
-                    const float dd = fma_(hi, hi, hr * hr);
                     Hl[64 * j] = usedj ? make_float2(hr / dd, -hi / dd) : make_float2(0.0f, 0.0f);
                 }
                 // the spec's xor tree over the 64 bins: steps 1,2,4,8 inside the row ...
@@ -734,17 +742,27 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 const bool has_idx = idx_all != nullptr, has_car = car_all != nullptr;
                 const int nbu = __builtin_amdgcn_readfirstlane(n_bpsc);      // the loop ran: some lane is active, but
                 const bool uniform = __all(!act || n_bpsc == nbu) && __builtin_amdgcn_readfirstlane((int)act);
-                if (uniform) {
-                    if (nbu == 1)      store_bins<1>(Y, carrier, act, q, idx, car, llr, has_idx, has_car, want_llr);
-                    else if (nbu == 2) store_bins<2>(Y, carrier, act, q, idx, car, llr, has_idx, has_car, want_llr);
-                    else if (nbu == 4) store_bins<4>(Y, carrier, act, q, idx, car, llr, has_idx, has_car, want_llr);
-                    else               store_bins<6>(Y, carrier, act, q, idx, car, llr, has_idx, has_car, want_llr);
-                } else {
-                    store_bins<1>(Y, carrier, act && n_bpsc == 1, q, idx, car, llr, has_idx, has_car, want_llr);
-                    store_bins<2>(Y, carrier, act && n_bpsc == 2, q, idx, car, llr, has_idx, has_car, want_llr);
-                    store_bins<4>(Y, carrier, act && n_bpsc == 4, q, idx, car, llr, has_idx, has_car, want_llr);
-                    store_bins<6>(Y, carrier, act && n_bpsc == 6, q, idx, car, llr, has_idx, has_car, want_llr);
+                float wq[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+                const bool csi = prm.llr_csi != 0 && llr_all != nullptr;     // wave-uniform
+                if (csi) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) wq[j] = Wl[64 * j];
                 }
+#define WR_STORE(NB, OK)                                                                                        \
+                { if (csi) store_bins<NB, true>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq);      \
+                  else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq); }
+                if (uniform) {
+                    if (nbu == 1)      WR_STORE(1, act)
+                    else if (nbu == 2) WR_STORE(2, act)
+                    else if (nbu == 4) WR_STORE(4, act)
+                    else               WR_STORE(6, act)
+                } else {
+                    WR_STORE(1, act && n_bpsc == 1)
+                    WR_STORE(2, act && n_bpsc == 2)
+                    WR_STORE(4, act && n_bpsc == 4)
+                    WR_STORE(6, act && n_bpsc == 6)
+                }
+#undef WR_STORE
                 if (act) n_out = q + 1;
             }
         }

@@ -118,6 +118,9 @@ typedef struct wifirx_config {
  * and one frame per wave (latency; ~0.2 ms per frame).  Batches of up to this many frames take the second one
  * (default 16384; 0 = always the first). */
 #define WIFIRX_P_DECODE_SMALL_MAX 6
+/* 1: every LLR is multiplied by |H|^2 of its sub-carrier (the LS channel estimate of the two long training
+ * symbols; the optional channel-state weight of SURVEY.md section 8 row a7).  Default 0: plain max-log LLRs. */
+#define WIFIRX_P_LLR_CSI 7
 
 typedef struct wifirx_handle wifirx_handle;
 

@@ -51,6 +51,7 @@ typedef struct orc_params {
     int32_t max_sym;      /* output capacity per frame (data symbols) */
     int32_t llr_bits;     /* 0: no llr */
     int32_t chan_est;     /* WIFIRX_EQ_LS / LMS / COMB / STA */
+    int32_t llr_csi;      /* 1: every LLR is multiplied by |H|^2 of its sub-carrier (LS estimate of the preamble) */
 } orc_params;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -676,6 +677,8 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     sp_sincos_q(Qp * 16u, &u16.im, &u16.re);
     c32 prev[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
     c32 H[64], G[64], DH[64];                                   /* DH: running estimate of COMB / STA */
+    float W[64];                                                /* |H|^2 of the LS estimate: the LLR weight (llr_csi) */
+    memset(W, 0, sizeof W);
     memset(H, 0, sizeof H);
     memset(G, 0, sizeof G);
     memset(DH, 0, sizeof DH);
@@ -865,6 +868,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 }
                 snr = (float)(10 * log10(signal / noise / 2));
             }
+            for (int i = 6; i <= 58; i++) if (i != 32) W[i] = fmaf(H[i].im, H[i].im, H[i].re * H[i].re);
             if (prm->chan_est == WIFIRX_EQ_STA) memcpy(DH, H, sizeof DH);     /* STA starts from the LS estimate */
             fr->snr_db = snr;
             if (csi) {            /* channel state: the LS estimate on the 52 occupied bins, ascending */
@@ -873,6 +877,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             }
         } else {
             uint8_t bits48[48];
+            int     bin48[48];
             c32     sym48[48];
             c32     HU[64];                                     /* STA: per-bin estimates of this symbol */
             memset(HU, 0, sizeof HU);
@@ -917,6 +922,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                     yq.re = crealf(v); yq.im = cimagf(v);
                 }
                 sym48[c] = yq;
+                bin48[c] = i;
                 bits48[c] = decide(yq, nb);
                 c++;
             }
@@ -962,8 +968,12 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 if (idx) memcpy(idx + (size_t)q * 48, bits48, 48);
                 if (eq) memcpy(eq + (size_t)q * 48, sym48, sizeof sym48);
                 if (llr && prm->llr_bits >= n_bpsc)
-                    for (int k = 0; k < 48; k++)
-                        llr_of(sym48[k], n_bpsc, llr + ((size_t)q * 48 + k) * n_bpsc);
+                    for (int k = 0; k < 48; k++) {
+                        float* lp = llr + ((size_t)q * 48 + k) * n_bpsc;
+                        llr_of(sym48[k], n_bpsc, lp);
+                        if (prm->llr_csi)                       /* spec rule 13: channel-state weight */
+                            for (int b = 0; b < n_bpsc; b++) lp[b] = lp[b] * W[bin48[k]];
+                    }
                 n_out = q + 1;
             }
         }

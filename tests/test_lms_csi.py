@@ -94,3 +94,42 @@ def test_lms_stream_mode(orc):
         L = int(got["frames"]["psdu_len"][k])
         assert np.array_equal(got["psdu"][k, :L], opsdu[k, :L])
     rx.close()
+
+
+def test_llr_csi_weight_is_the_preamble_channel_power(orc):
+    """WIFIRX_P_LLR_CSI (row a7, optional weight): every LLR times |H|^2 of its sub-carrier, H = the LS estimate the
+    CSI export delivers; signs, hence hard decisions, unchanged"""
+    taps = np.array([[1.0, 0.4 + 0.3j, 0.2j]], dtype=np.complex64)
+    for enc in (0, 2, 5, 7):
+        iq, slot_len, tx = make_slots(6, enc, snr_db=28.0, seed=120 + enc, taps=np.repeat(taps, 6, axis=0))
+        nb = txgen.RATE_TABLE[enc][0]
+        a = orc.demod_batch(iq, slot_len, orc.make_params(max_sym=tx.n_sym, llr_bits=nb), want_csi=True)
+        b = orc.demod_batch(iq, slot_len, orc.make_params(max_sym=tx.n_sym, llr_bits=nb, llr_csi=1), want_csi=True)
+        assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["frames"], b["frames"])
+        data_bins = [i for i in range(6, 59) if i not in (11, 25, 32, 39, 53)]
+        csi_pos = {i: k for k, i in enumerate(i for i in range(6, 59) if i != 32)}
+        w = np.abs(a["csi"][:, [csi_pos[i] for i in data_bins]].astype(np.complex128)) ** 2          # [frames, 48]
+        la = a["llr"].reshape(6, tx.n_sym, 48, nb)
+        lb = b["llr"].reshape(6, tx.n_sym, 48, nb)
+        assert np.allclose(lb, la * w[:, None, :, None], rtol=2e-6, atol=0)
+        assert np.array_equal(np.signbit(la), np.signbit(lb))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chan_est", [0, 3])
+@pytest.mark.parametrize("encoding", [0, 3, 4, 7])
+def test_llr_csi_bit_exact_on_gpu(orc, encoding, chan_est):
+    from wifirx import capi
+    iq, slot_len, tx = make_slots(20, encoding, snr_db=22.0, seed=130 + encoding)
+    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=6, chan_est=chan_est)
+    rx.set_param(capi.P_LLR_CSI, 1)
+    r = rx.demod_batch(iq, slot_len)
+    o = orc.demod_batch(iq, slot_len, orc.make_params(max_sym=tx.n_sym, llr_bits=6, chan_est=chan_est, llr_csi=1))
+    assert np.array_equal(r["frames"], o["frames"]) and np.array_equal(r["idx"], o["idx"])
+    assert np.array_equal(r["llr"].view(np.uint32), o["llr"].view(np.uint32))
+    rx.set_param(capi.P_LLR_CSI, 0)
+    r0 = rx.demod_batch(iq, slot_len)
+    o0 = orc.demod_batch(iq, slot_len, orc.make_params(max_sym=tx.n_sym, llr_bits=6, chan_est=chan_est))
+    assert np.array_equal(r0["llr"].view(np.uint32), o0["llr"].view(np.uint32))
+    assert not np.array_equal(r0["llr"], r["llr"])
+    rx.close()
