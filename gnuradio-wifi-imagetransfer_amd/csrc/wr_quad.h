@@ -282,7 +282,7 @@ __device__ __forceinline__ float row_xor_sum16(float v)
 
 // a6 + a7 stores of one lane's four bins for constellation NB (compile-time: no per-lane branching on it).
 // ok = row active; the pointers are the row's output slices.
-// CSI: every LLR is multiplied by w[j] = |H|^2 of its sub-carrier (spec rule 13).
+// CSI: every LLR is multiplied by w[j] = |H|^2 of its sub-carrier (spec rule 12).
 template <int NB, bool CSI>
 __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrier)[4], bool ok, int q,
                                            uint8_t* __restrict__ idx, float2* __restrict__ car,

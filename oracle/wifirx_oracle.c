@@ -971,7 +971,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                     for (int k = 0; k < 48; k++) {
                         float* lp = llr + ((size_t)q * 48 + k) * n_bpsc;
                         llr_of(sym48[k], n_bpsc, lp);
-                        if (prm->llr_csi)                       /* spec rule 13: channel-state weight */
+                        if (prm->llr_csi)                       /* spec rule 12: channel-state weight */
                             for (int b = 0; b < n_bpsc; b++) lp[b] = lp[b] * W[bin48[k]];
                     }
                 n_out = q + 1;
