@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""The demod and decode_mac kernels on frame geometries other than bench.py's config 2: device-resident batches
+generated like bench.py's (host templates -> Philox AWGN + CFO on the GPU), kernel time by HIP events, throughput
+and the algorithmic-bytes fraction of the 8 TB/s roofline (SURVEY.md 8(d) formula).  Prints one JSON line.
+
+    python tools/other_configs.py [frames=1000000]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gnuradio-wifi-imagetransfer_amd"))
+from wifirx import capi, txgen  # noqa: E402
+
+CASES = [   # name, encoding, PSDU bytes, slot length
+    ("config 3 geometry: 64-QAM 3/4, 294 B, slot 1472", 7, 294, 1472),
+    ("config 1 geometry: BPSK 1/2, 294 B, slot 8576", 0, 294, 8576),
+    ("16-QAM 1/2, 1000 B, slot 7424", 4, 1000, 7424),
+    ("config 2: QPSK 1/2, 294 B, slot 4608", 2, 294, 4608),
+]
+
+
+def main():
+    n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+    res = []
+    for name, enc, plen, slot_len in CASES:
+        n_sym = txgen.n_sym_for(plen, enc)
+        n_bpsc = txgen.RATE_TABLE[enc][0]
+        tx = txgen.encode_psdus(txgen.make_psdus(256, plen, seed=5), enc)
+        assert 160 + tx.samples.shape[1] <= slot_len
+        rx = capi.WifiRx(max_sym=n_sym, llr_bits=n_bpsc)
+        slots = rx.alloc(n_frames * slot_len * 8)
+        dev = rx.alloc_out(n_frames, psdu_stride=((plen + 63) // 64) * 64)
+        rx.synth_slots(tx.samples, slots.ptr, slot_len, n_frames, 160, 25.0, 0.037, 77)
+        rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=1)
+        ms = rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=5)
+        rx.decode_batch_dev(n_frames, dev); rx.sync()
+        t = time.perf_counter()
+        rx.decode_batch_dev(n_frames, dev); rx.sync()
+        dec_ms = (time.perf_counter() - t) * 1e3
+        fr = dev["frames"].download(capi.FRAME_DTYPE, n_frames)
+        bpf = 8 * slot_len + 48 * n_sym * (1 + 4 * n_bpsc) + 32
+        res.append({"case": name, "frames": n_frames, "n_sym": n_sym, "demod_ms": ms,
+                    "gsamples_per_s": n_frames * slot_len / ms / 1e6, "algorithmic_bytes_per_frame": bpf,
+                    "roofline_frac": bpf * n_frames / (ms * 1e-3) / 8e12, "decode_mac_ms": dec_ms,
+                    "crc_ok": int(((fr["flags"] & capi.F_CRC_OK) != 0).sum())})
+        rx.free_out(dev); slots.free(); rx.close()
+    print(json.dumps({"cases": res}))
+
+
+if __name__ == "__main__":
+    main()
