@@ -39,8 +39,8 @@ int main()
     srand(1);
     int n_fma = 0, n_muladd = 0, n_other = 0, total = 0;
     for (int rep = 0; rep < 2000; rep++) {
-        for (int i = 0; i < 64; i++) { ha[i] = ldexpf((float)rand() / RAND_MAX - 0.5f, rand() % 40 - 20); hb[i] = ldexpf((float)rand() / RAND_MAX - 0.5f, rand() % 40 - 20); }
-        for (int i = 0; i < 256; i++) hc[i] = ldexpf((float)rand() / RAND_MAX - 0.5f, rand() % 40 - 20);
+        for (int i = 0; i < 64; i++) { ha[i] = ldexpf((float)rand() / (float)RAND_MAX - 0.5f, rand() % 40 - 20); hb[i] = ldexpf((float)rand() / (float)RAND_MAX - 0.5f, rand() % 40 - 20); }
+        for (int i = 0; i < 256; i++) hc[i] = ldexpf((float)rand() / (float)RAND_MAX - 0.5f, rand() % 40 - 20);
         (void)hipMemcpy(da, ha, 256, hipMemcpyHostToDevice); (void)hipMemcpy(db, hb, 256, hipMemcpyHostToDevice); (void)hipMemcpy(dc, hc, 1024, hipMemcpyHostToDevice);
         hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, da, db, dc, dd);
         (void)hipMemcpy(hd, dd, 1024, hipMemcpyDeviceToHost);
