@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "gnuradio-wifi-imagetransfer_amd"))
 sys.path.insert(0, ROOT)
 from wifirx import capi, txgen  # noqa: E402

@@ -3,7 +3,7 @@
 in rate, length, SNR, CFO, lead-in and channel (flat / multipath), for every equaliser.  The pytest parity cases
 are hand-picked and small; this is the bulk check behind them.  Prints one JSON line.
 
-    python tools/parity_campaign.py [n_frames=20000] [seed=1] [long]
+    python tests/campaigns/parity_campaign.py [n_frames=20000] [seed=1] [long]
 
 `long`: slots of 45056 samples, PSDUs up to 1530 bytes at every rate (up to 511 OFDM symbols: the longest frames
 decode_mac accepts, and the renormalisation of its 16-bit path metrics over 12 000+ trellis steps).
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "gnuradio-wifi-imagetransfer_amd"))
 sys.path.insert(0, ROOT)
 from wifirx import capi, txgen  # noqa: E402

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """How far is the numerics spec (what the HIP kernels equal bit for bit) from the upstream-literal evaluation of
 the same chain (libm, C99 complex arithmetic, double running sums: the oracle's LIBM mode)?  Both oracle modes on
-the random frames of tools/parity_campaign.py; CPU only.
+the random frames of tests/campaigns/parity_campaign.py; CPU only.
 
-    python tools/spec_vs_libm.py [n_frames=3000] [seed=11]
+    python tests/campaigns/spec_vs_libm.py [n_frames=3000] [seed=11]
 """
 import json
 import os
@@ -11,10 +11,10 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "gnuradio-wifi-imagetransfer_amd"))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import parity_campaign as pc  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 

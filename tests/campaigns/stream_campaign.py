@@ -4,7 +4,7 @@ shorter than sync_short's re-trigger distance, some frames cut off by the next o
 with a random WIFIRX_P_STREAM_BATCH, against the oracle's stream driver: same frames, same records, same
 decisions, same PSDUs.  Prints one JSON line.
 
-    python tools/stream_campaign.py [n_streams=40] [frames_per_stream=30] [seed=1]
+    python tests/campaigns/stream_campaign.py [n_streams=40] [frames_per_stream=30] [seed=1]
 """
 import json
 import os
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "gnuradio-wifi-imagetransfer_amd"))
 sys.path.insert(0, ROOT)
 from wifirx import capi, txgen  # noqa: E402
