@@ -67,6 +67,16 @@ def test_create_argument_checks():
         assert b"" != capi.lib().wifirx_last_error(None)
 
 
+def test_tools_and_examples_do_not_touch_the_oracle():
+    """only tests/ (its campaign scripts included), __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/"""
+    for sub in ("tools", "examples"):
+        for dp, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".hip")):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert "from oracle" not in txt and "import oracle" not in txt and "liboracle" not in txt, (dp, f)
+
+
 def test_product_does_not_touch_the_oracle():
     """nothing under the package or bench's timed path imports oracle/"""
     pkg = os.path.join(ROOT, "gnuradio-wifi-imagetransfer_amd")
