@@ -22,6 +22,7 @@ struct PolledFrame {
     std::vector<uint8_t>  psdu;
     std::vector<uint8_t>  idx;
     std::vector<float>    carrier;
+    float                 csi[104];
 };
 
 struct PendingTrig {
@@ -68,6 +69,7 @@ struct wifirx_handle {
     std::deque<PolledFrame>  queue;
     void*  s_trig = nullptr;  void* s_frames = nullptr;  void* s_idx = nullptr;  void* s_llr = nullptr;
     void*  s_car = nullptr;   void* s_psdu = nullptr;    uint32_t s_cap = 0;
+    void*  s_csi = nullptr;
 };
 
 namespace {
@@ -171,7 +173,7 @@ int wifirx_destroy(wifirx_handle* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi,
                      h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx, h->s_llr,
-                     h->s_car, h->s_psdu };
+                     h->s_car, h->s_psdu, h->s_csi };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->s_pack) (void)hipFree(h->s_pack);
     if (h->dec_masks) (void)hipFree(h->dec_masks);

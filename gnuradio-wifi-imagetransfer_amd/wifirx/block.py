@@ -31,7 +31,7 @@ LINKTYPE_IEEE802_11 = 105
 
 class wifi_phy_rx(grshim.sync_block):
     def __init__(self, bandwidth=10e6, chan_est=LS, encoding=0, frequency=5.89e9, sensitivity=0.56,
-                 max_sym=511, publish_carrier=True, device=0, batch_samples=1 << 20):
+                 max_sym=511, publish_carrier=True, device=0, batch_samples=1 << 20, publish_csi=False):
         grshim.sync_block.__init__(self, name="wifi_phy_rx", in_sig=[np.complex64], out_sig=None)
         self.bandwidth = float(bandwidth)
         self.chan_est = int(chan_est)
@@ -39,6 +39,7 @@ class wifi_phy_rx(grshim.sync_block):
         self.frequency = float(frequency)
         self.sensitivity = float(sensitivity)
         self.publish_carrier = bool(publish_carrier)
+        self.publish_csi = bool(publish_csi)      # "csi" entry of the mac_out dictionary, as upstream's frame_equalizer tags it
         self.message_port_register_out(grshim.intern("mac_out"))
         self.message_port_register_out(grshim.intern("carrier"))
         self._rx = capi.WifiRx(bandwidth=self.bandwidth, frequency=self.frequency, sensitivity=self.sensitivity,
@@ -120,7 +121,7 @@ class wifi_phy_rx(grshim.sync_block):
 
     def _publish(self):
         while True:
-            r = self._rx.poll(cap=64, psdu_stride=2048)
+            r = self._rx.poll(cap=64, psdu_stride=2048, want_csi=self.publish_csi)
             fr = r["frames"]
             if len(fr) == 0:
                 return
@@ -142,6 +143,8 @@ class wifi_phy_rx(grshim.sync_block):
                     "freq_offset": tag * self.bandwidth / (2 * math.pi),
                     "dlt": LINKTYPE_IEEE802_11,
                 }
+                if self.publish_csi:
+                    meta["csi"] = r["csi"][i].copy()
                 blob = r["psdu"][i, :int(f["psdu_len"]) - 4].copy()
                 self.message_port_pub(grshim.intern("mac_out"), grshim.make_pdu(meta, blob))
 

@@ -29,7 +29,7 @@ assert FRAME_DTYPE.itemsize == 32
 
 EXPORTS = [
     "wifirx_create", "wifirx_destroy", "wifirx_last_error", "wifirx_abi_version", "wifirx_set_param",
-    "wifirx_get_stats", "wifirx_demod_batch", "wifirx_decode_batch", "wifirx_push", "wifirx_poll",
+    "wifirx_get_stats", "wifirx_demod_batch", "wifirx_decode_batch", "wifirx_push", "wifirx_poll", "wifirx_poll_csi",
     "wifirx_sync", "wifirx_stream", "wifirx_synth_slots", "wifirx_dev_alloc", "wifirx_dev_free",
     "wifirx_memcpy_h2d", "wifirx_memcpy_d2h", "wifirx_time_demod",
 ]
@@ -76,6 +76,8 @@ _lib.wifirx_decode_batch.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Out)]
 _lib.wifirx_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 _lib.wifirx_poll.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                              C.c_uint32, C.POINTER(C.c_uint32)]
+_lib.wifirx_poll_csi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_uint32, C.POINTER(C.c_uint32)]
 _lib.wifirx_sync.argtypes = [C.c_void_p]
 _lib.wifirx_synth_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
                                     C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_uint64,
@@ -267,20 +269,21 @@ class WifiRx:
         iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
         self._check(_lib.wifirx_push(self._h, _np_ptr(iq), iq.size, 0))
 
-    def poll(self, cap=256, psdu_stride=2048, want_idx=False):
+    def poll(self, cap=256, psdu_stride=2048, want_idx=False, want_csi=False):
         """Finished frames of the stream, oldest first (at most `cap`).  The landing buffers are kept between calls
         (a scheduler polls after every work()); what is returned are copies of the filled part."""
         ms = self.cfg.max_sym
-        key = (cap, psdu_stride, bool(want_idx))
+        key = (cap, psdu_stride, bool(want_idx), bool(want_csi))
         if getattr(self, "_poll_key", None) != key:
             self._poll_key = key
             self._poll_buf = (np.zeros(cap, dtype=FRAME_DTYPE), np.zeros((cap, psdu_stride), dtype=np.uint8),
                               np.zeros((cap, ms, 48), dtype=np.uint8) if want_idx else None,
-                              np.zeros((cap, ms, 48), dtype=np.complex64) if self.cfg.want_carrier else None)
-        frames, psdu, idx, car = self._poll_buf
+                              np.zeros((cap, ms, 48), dtype=np.complex64) if self.cfg.want_carrier else None,
+                              np.zeros((cap, 52), dtype=np.complex64) if want_csi else None)
+        frames, psdu, idx, car, csi = self._poll_buf
         n = C.c_uint32(0)
-        self._check(_lib.wifirx_poll(self._h, _np_ptr(frames), _np_ptr(psdu), psdu_stride, _np_ptr(idx),
-                                     _np_ptr(car), cap, C.byref(n)))
+        self._check(_lib.wifirx_poll_csi(self._h, _np_ptr(frames), _np_ptr(psdu), psdu_stride, _np_ptr(idx),
+                                         _np_ptr(car), _np_ptr(csi), cap, C.byref(n)))
         n = n.value
         return dict(frames=frames[:n].copy(), psdu=psdu[:n].copy(), idx=None if idx is None else idx[:n].copy(),
-                    carrier=None if car is None else car[:n].copy())
+                    carrier=None if car is None else car[:n].copy(), csi=None if csi is None else csi[:n].copy())

@@ -198,6 +198,12 @@ int  wifirx_push(wifirx_handle* h, const float* iq, size_t n, int iq_on_device);
 int  wifirx_poll(wifirx_handle* h, wifirx_frame* frames, uint8_t* psdu, uint32_t psdu_stride,
                  uint8_t* idx, float* carrier, uint32_t cap, uint32_t* n_out);
 
+/* wifirx_poll that also delivers the channel state of every frame: csi + i*104 floats = the LS estimate on the 52
+ * occupied sub-carriers (re, im), the `csi` entry upstream's frame_equalizer puts into the frame's tag dictionary
+ * (read by ieee802_11.extract_csi, gnu_radio/IRS_AP.grc:640-654).  csi may be NULL. */
+int  wifirx_poll_csi(wifirx_handle* h, wifirx_frame* frames, uint8_t* psdu, uint32_t psdu_stride,
+                     uint8_t* idx, float* carrier, float* csi, uint32_t cap, uint32_t* n_out);
+
 /* block until everything queued on the handle's stream has finished */
 int  wifirx_sync(wifirx_handle* h);
 

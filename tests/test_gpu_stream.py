@@ -106,3 +106,40 @@ def test_block_publishes_reference_pdus(orc):
         rx.set_chan_est(eq)
     with pytest.raises(Exception):
         rx.set_chan_est(7)
+
+
+def test_stream_csi_equals_batch_csi_and_reaches_the_pdu(orc):
+    """wifirx_poll_csi: the channel state of a frame found in the stream is the LS estimate batch mode (and the
+    oracle) compute for the same samples; the block puts it into the mac_out dictionary as upstream's
+    frame_equalizer does (`csi`, 52 complex values)"""
+    from wifirx import block, capi, grshim
+    taps = np.array([[1.0, 0.3 - 0.2j, 0.1j]], dtype=np.complex64)
+    psdu = txgen.make_psdus(1, 200, seed=77)
+    tx = txgen.encode_psdus(psdu, 4)
+    total = ((300 + tx.samples.shape[1] + 700 + 63) // 64) * 64
+    x = txgen.impair(tx.samples, 27.0, cfo=0.012, lead=300, total=total, seed=6, taps=taps).reshape(-1)
+    o = orc.demod_batch(x, total, orc.make_params(max_sym=tx.n_sym), want_csi=True)
+    assert o["frames"]["flags"][0] & orc.F_COMPLETE
+    rx = capi.WifiRx(max_sym=511)
+    for p in range(0, x.size, 1000):
+        rx.push(x[p:p + 1000])
+    rx._check(capi.lib().wifirx_push(rx._h, None, 0, 0))
+    got = rx.poll(cap=8, want_csi=True)
+    rx.close()
+    assert len(got["frames"]) == 1 and got["frames"]["flags"][0] & capi.F_CRC_OK
+    assert np.array_equal(got["csi"][0].view(np.uint64), o["csi"][0].view(np.uint64))
+    pdus = []
+    blk = block.wifi_phy_rx(bandwidth=20e6, publish_carrier=False, publish_csi=True)
+
+    class sink(grshim.basic_block):
+        def __init__(self):
+            grshim.basic_block.__init__(self, name="sink", in_sig=None, out_sig=None)
+            self.message_port_register_in(grshim.intern("in"))
+            self.set_msg_handler(grshim.intern("in"), lambda m: pdus.append(grshim.to_python(m)))
+    s = sink()
+    grshim.msg_connect(blk, "mac_out", s, "in")
+    grshim.run_stream(blk, x, chunk=4096)
+    assert len(pdus) == 1
+    meta, blob = pdus[0]
+    assert meta["csi"].shape == (52,) and np.array_equal(meta["csi"].view(np.uint64), o["csi"][0].view(np.uint64))
+    assert np.array_equal(blob, psdu[0][:-4])
