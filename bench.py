@@ -74,9 +74,16 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())      # a launcher that shows every rank one device only
     torch.cuda.set_device(local_rank)
     dist = None
+    # "nccl" is RCCL on ROCm.  WIFIRX_BENCH_BACKEND=gloo is for rehearsing the multi-rank code path on a box with
+    # fewer GPUs than ranks (the collectives then go through host memory; never used for a reported number).
+    backend = os.environ.get("WIFIRX_BENCH_BACKEND", "nccl")
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from wifirx import capi, txgen
     from wifirx import dist as wdist
@@ -123,7 +130,7 @@ def main():
         rx.sync()
         t_b = time.perf_counter()
         if world > 1:
-            wdist.all_gather_pdus(psdu_t, frames_t)
+            wdist.all_gather_pdus(psdu_t.to(coll_dev), frames_t.to(coll_dev))
             torch.cuda.synchronize()
         return (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3
 
@@ -142,7 +149,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -207,7 +214,8 @@ def main():
                 "frames_per_gpu": n_frames, "slot_len": SLOT_LEN, "encoding": "QPSK_1_2",
                 "outputs": "48 u8 decisions + 96 f32 LLRs per data symbol, 32 B frame record"
                            + ("; decode_mac + PSDU" if do_decode else ""),
-                "parallelism": "frames sharded %d-way, no collective on the hot path" % world if world > 1 else "1 GPU",
+                "parallelism": ("frames sharded %d-way, no collective on the hot path" % world if world > 1 else "1 GPU")
+                               + ("" if backend == "nccl" else " [REHEARSAL: %s backend]" % backend),
             },
             "gsamples_per_s": value / 1e9,
             "msymbols_per_s": float(n_frames) * (n_sym + 3) * world * args.steps / elapsed / 1e6,
