@@ -49,7 +49,21 @@ def main():
                     "roofline_frac": bpf * n_frames / (ms * 1e-3) / 8e12, "decode_mac_ms": dec_ms,
                     "crc_ok": int(((fr["flags"] & capi.F_CRC_OK) != 0).sum())})
         rx.free_out(dev); slots.free(); rx.close()
-    print(json.dumps({"cases": res}))
+    # the other equalisers on config 2's geometry (their kernel instances are parity-tested, not tuned)
+    eqs = []
+    name, enc, plen, slot_len = CASES[-1]
+    n_sym, n_bpsc = txgen.n_sym_for(plen, enc), txgen.RATE_TABLE[enc][0]
+    tx = txgen.encode_psdus(txgen.make_psdus(256, plen, seed=5), enc)
+    for ce, en in enumerate(("LS", "LMS", "COMB", "STA")):
+        rx = capi.WifiRx(max_sym=n_sym, llr_bits=n_bpsc, chan_est=ce)
+        slots = rx.alloc(n_frames * slot_len * 8)
+        dev = rx.alloc_out(n_frames, psdu_stride=320)
+        rx.synth_slots(tx.samples, slots.ptr, slot_len, n_frames, 160, 25.0, 0.037, 77)
+        rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=1)
+        ms = rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=5)
+        eqs.append({"chan_est": en, "demod_ms": ms, "gsamples_per_s": n_frames * slot_len / ms / 1e6})
+        rx.free_out(dev); slots.free(); rx.close()
+    print(json.dumps({"cases": res, "equalisers_on_config_2": eqs}))
 
 
 if __name__ == "__main__":
