@@ -7,21 +7,29 @@ A step = one pass of the whole RX hot path (autocorrelation + sync_short + sync_
 LS equalise + hard demap + LLR, one fused HIP kernel) over one device-resident batch of
 synthetic 802.11a frames: BASELINE.json configs[1] = 1,000,000 QPSK-1/2 frames of 294-byte
 PSDUs at 20 MHz, AWGN SNR 20 dB, per-frame CFO within +-20 ppm, one frame per 4608-sample slot.
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank owns its own
-1M-frame shard (weak scaling); the hot path has no exchange step, so the timed region is the same
-at every N.  What follows the hot path -- decode_mac on the device and, for N > 1, the RCCL
-all-gather that reassembles the decoded PDU stream on every rank -- is run and timed separately
-after the timed region and reported in the extra object "pdu_leg" (never part of `value`).
+
+N > 1: one process per GPU.  `python bench.py --gpus N` starts its own ranks (a child
+`python -m torch.distributed.run ... bench.py --gpus N`, spawned before this process has touched
+the GPU or imported torch; it never re-execs); launched under torch.distributed.run it is a rank.
+Every rank owns its own 1M-frame shard (weak scaling); the hot path has no exchange step, so the
+timed region is the same at every N.  What follows the hot path -- decode_mac on the device and, for
+N > 1, the RCCL all-gather that reassembles the decoded PDU stream on every rank (chunked: the
+collective of chunk c runs while decode_mac works on chunk c + 1; buffers allocated once) -- is run
+and timed separately after the timed region and reported in "pdu_leg" (never part of `value`).
 
 Rank 0 prints ONE JSON line (see the round prompt for the contract) with the extra objects
-"roofline" (dominant kernel, algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak)
-and "cpu_baseline" (the oracle, timed on this host's cores on a bounded sample of the same batch).
+"roofline" (dominant kernel: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak, and the
+same on the bytes the PMC counters saw move), "cpu_baseline" (the oracle, timed on this host's cores on
+a bounded sample of the same batch), "host_path" (the drop-in block's work() fed with 8192-item host
+chunks), "samples_to_pdu" (demod + decode_mac) and "variants" (config 2 with CFO = 0).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,7 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "gnuradio-wifi-imagetransfer_amd"))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12          # bytes/s, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12          # bytes/s, MI355X_MICROARCH.md (spec)
+HBM_ACHIEVABLE = 6.29e12   # bytes/s, MI355X_MICROARCH.md (measured float4 copy)
 PSDU_LEN = 294
 ENCODING = 2               # QPSK 1/2
 SLOT_LEN = 4608
@@ -41,6 +50,7 @@ BANDWIDTH = 20e6
 FREQUENCY = 5.89e9
 CFO_MAX = 2 * np.pi * 20e-6 * FREQUENCY / BANDWIDTH    # +-20 ppm of the carrier, rad/sample
 N_TEMPLATES = 1024
+PSDU_STRIDE = 320
 
 
 def algorithmic_bytes_per_frame(slot_len, n_sym, n_bpsc):
@@ -48,35 +58,86 @@ def algorithmic_bytes_per_frame(slot_len, n_sym, n_bpsc):
     return 8 * slot_len + 48 * n_sym * (1 + 4 * n_bpsc) + 32
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (config 2: 1M)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="target wall time of the cpu_baseline leg")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline, host_path and variant legs")
     ap.add_argument("--decode", action="store_true", help="put decode_mac (and the all-gather) INSIDE every timed step")
     ap.add_argument("--pdu-steps", type=int, default=2, help="steps of the separate decode_mac + all-gather leg (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--gather-chunks", type=int, default=2, help="frame ranges the PDU all-gather is cut into (N > 1)")
+    ap.add_argument("--host-samples", type=int, default=24_000_000, help="samples pushed through work() in the host_path leg")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n: int) -> int:
+    """Parent of a multi-GPU run: start n ranks under torch.distributed.run and wait.  Nothing here touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def latest_profile(suffix):
+    """newest profiles/*<suffix> as a dict (None if absent) -- PMC passes and the memory-floor probe cannot run inside
+    a bench run, their committed summaries are quoted instead"""
+    try:
+        d = os.path.join(ROOT, "profiles")
+        cands = sorted(f for f in os.listdir(d) if f.endswith(suffix))
+        with open(os.path.join(d, cands[-1])) as f:
+            j = json.load(f)
+        j["_file"] = "profiles/" + cands[-1]
+        return j
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    stub = os.environ.get("WIFIRX_BENCH_STUB") == "1"        # CPU rehearsal of the launcher + all-gather plumbing (tests/)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus), file=sys.stderr)
-            sys.exit(2)
-    import torch
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; the product has no CPU fallback", file=sys.stderr)
+        print("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
-    local_rank %= max(1, torch.cuda.device_count())      # a launcher that shows every rank one device only
-    torch.cuda.set_device(local_rank)
-    dist = None
+    import torch
     # "nccl" is RCCL on ROCm.  WIFIRX_BENCH_BACKEND=gloo is for rehearsing the multi-rank code path on a box with
     # fewer GPUs than ranks (the collectives then go through host memory; never used for a reported number).
-    backend = os.environ.get("WIFIRX_BENCH_BACKEND", "nccl")
+    backend = "gloo" if stub else os.environ.get("WIFIRX_BENCH_BACKEND", "nccl")
+    if not stub:
+        n_dev = torch.cuda.device_count()
+        if n_dev == 0 or not torch.cuda.is_available():
+            print("bench.py: no GPU visible; the product has no CPU fallback", file=sys.stderr)
+            sys.exit(2)
+        if world > n_dev and backend == "nccl":
+            print("bench.py: %d ranks but %d GPUs (WIFIRX_BENCH_BACKEND=gloo rehearses on fewer)" % (world, n_dev), file=sys.stderr)
+            sys.exit(2)
+        local_rank %= n_dev
+        torch.cuda.set_device(local_rank)
+    dist = None
     coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
@@ -85,14 +146,19 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from wifirx import capi, txgen
     from wifirx import dist as wdist
 
     n_frames = args.frames
-    n_sym = txgen.n_sym_for(PSDU_LEN, ENCODING)
-    n_bpsc = txgen.RATE_TABLE[ENCODING][0]
     do_decode = args.decode                 # decode inside the timed step (off by default)
     want_pdus = do_decode or args.pdu_steps > 0
+
+    if stub:
+        run_stub(args, rank, world, dist, wdist, torch)
+        return
+
+    from wifirx import capi, txgen
+    n_sym = txgen.n_sym_for(PSDU_LEN, ENCODING)
+    n_bpsc = txgen.RATE_TABLE[ENCODING][0]
 
     # ---- synthetic input: host templates -> device slots (Philox AWGN + CFO on the GPU) ----
     psdu = txgen.make_psdus(N_TEMPLATES, PSDU_LEN, seed=2025 + rank)
@@ -104,16 +170,22 @@ def main():
                      llr_bits=n_bpsc, want_carrier=False, device=local_rank)
     iq = torch.empty((n_frames, SLOT_LEN, 2), dtype=torch.float32, device="cuda")
     cfo = torch.empty(n_frames, dtype=torch.float32, device="cuda")
-    rx.synth_slots(tx.samples, iq.data_ptr(), SLOT_LEN, n_frames, LEAD, SNR_DB, float(CFO_MAX),
-                   1234 + 7919 * rank, cfo.data_ptr())
+    synth_seed = 1234 + 7919 * rank
+    rx.synth_slots(tx.samples, iq.data_ptr(), SLOT_LEN, n_frames, LEAD, SNR_DB, float(CFO_MAX), synth_seed, cfo.data_ptr())
     # outputs as torch tensors (device memory + RCCL plumbing only)
     frames_t = torch.zeros((n_frames, 32), dtype=torch.uint8, device="cuda")
     idx_t = torch.zeros((n_frames, n_sym * 48), dtype=torch.uint8, device="cuda")
     llr_t = torch.zeros((n_frames, n_sym * 48 * n_bpsc), dtype=torch.float32, device="cuda")
-    psdu_stride = 320
-    psdu_t = torch.zeros((n_frames, psdu_stride), dtype=torch.uint8, device="cuda") if want_pdus else None
+    psdu_t = torch.zeros((n_frames, PSDU_STRIDE), dtype=torch.uint8, device="cuda") if want_pdus else None
     out = capi.Out(frames_t.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), None,
-                   psdu_t.data_ptr() if want_pdus else None, psdu_stride if want_pdus else 0, 1, None)
+                   psdu_t.data_ptr() if want_pdus else None, PSDU_STRIDE if want_pdus else 0, 1, None)
+    gather = None
+    if world > 1 and want_pdus:
+        gather = wdist.ChunkedPduGather(n_frames, PSDU_STRIDE, args.gather_chunks, coll_dev)
+    lib_stream = torch.cuda.ExternalStream(rx.stream_ptr())      # the handle's own HIP stream, as torch sees it
+    # the zero fills above ran on torch's stream, the library launches on its own: order them once
+    torch.cuda.synchronize()
+
     def step():
         """one pass of the hot path; returns the demod kernel's HIP-event time in ms"""
         ms = capi.C.c_float(0)
@@ -123,15 +195,32 @@ def main():
             pdu_step()
         return ms.value
 
+    def decode_range(lo, hi):
+        o = capi.Out(frames_t.data_ptr() + lo * 32, idx_t.data_ptr() + lo * n_sym * 48, None, None,
+                     psdu_t.data_ptr() + lo * PSDU_STRIDE, PSDU_STRIDE, 1, None)
+        rx._check(capi.lib().wifirx_decode_batch(rx._h, hi - lo, capi.C.byref(o)))
+
     def pdu_step():
-        """decode_mac over the demodulated batch (+ all-gather of PSDUs and frame records for N > 1)"""
+        """decode_mac over the demodulated batch; for N > 1 chunk by chunk, every chunk's all-gather (PSDUs + frame
+        records, RCCL's own stream) overlapping the next chunk's decode.  Returns (decode ms, exposed all-gather ms)."""
         t_a = time.perf_counter()
-        rx._check(capi.lib().wifirx_decode_batch(rx._h, n_frames, capi.C.byref(out)))
+        if gather is None:
+            decode_range(0, n_frames)
+            rx.sync()
+            return (time.perf_counter() - t_a) * 1e3, 0.0
+        for c in range(gather.n_chunks):
+            lo, hi = gather.chunk_range(c)
+            decode_range(lo, hi)
+            if coll_dev == "cuda":
+                with torch.cuda.stream(lib_stream):      # the collective waits for this chunk's decode only
+                    gather.gather_chunk(c, psdu_t, frames_t, async_op=True)
+            else:                                        # gloo rehearsal: through host memory, no overlap
+                rx.sync()
+                gather.gather_chunk(c, psdu_t.cpu(), frames_t.cpu(), async_op=False)
         rx.sync()
         t_b = time.perf_counter()
-        if world > 1:
-            wdist.all_gather_pdus(psdu_t.to(coll_dev), frames_t.to(coll_dev))
-            torch.cuda.synchronize()
+        gather.wait()
+        torch.cuda.synchronize()
         return (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3
 
     def barrier():
@@ -146,6 +235,7 @@ def main():
     kernel_ms = 0.0
     for _ in range(args.steps):
         kernel_ms += step()
+    t_own = time.perf_counter() - t0          # this rank alone, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -157,6 +247,11 @@ def main():
     value = total_samples / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     kernel_ms_avg = kernel_ms / args.steps
+    per_rank = [{"rank": rank, "kernel_ms": kernel_ms_avg, "gsamples_per_s": float(n_frames) * SLOT_LEN * args.steps / t_own / 1e9}]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
 
     # ---- the leg behind the hot path: decode_mac (+ RCCL all-gather of the PDUs), timed on its own ----
     pdu_leg = None
@@ -170,14 +265,40 @@ def main():
             ag_ms.append(a)
         barrier()
         leg = (time.perf_counter() - t1) / args.pdu_steps * 1e3
-        pdu_leg = {"decode_mac_ms": float(np.median(dec_ms)), "all_gather_ms": float(np.median(ag_ms)) if world > 1 else None,
-                   "ms_per_step": leg, "psdu_stride": psdu_stride,
-                   "note": "decode_mac on the device + RCCL all_gather_into_tensor of PSDUs and frame records; not in `value`"}
+        ag_alone = None
+        if gather is not None:          # the same exchange with nothing to hide behind
+            barrier()
+            t2 = time.perf_counter()
+            for c in range(gather.n_chunks):
+                if coll_dev == "cuda":
+                    gather.gather_chunk(c, psdu_t, frames_t, async_op=True)
+                else:
+                    gather.gather_chunk(c, psdu_t.cpu(), frames_t.cpu(), async_op=False)
+            gather.wait()
+            barrier()
+            ag_alone = (time.perf_counter() - t2) * 1e3
+        pdu_leg = {"decode_mac_ms": float(np.median(dec_ms)),
+                   "all_gather_ms": ag_alone, "all_gather_exposed_ms": float(np.median(ag_ms)) if world > 1 else None,
+                   "gather_chunks": gather.n_chunks if gather is not None else None,
+                   "ms_per_step": leg, "psdu_stride": PSDU_STRIDE,
+                   "gathered_bytes_per_rank": (PSDU_STRIDE + 32) * n_frames * world if world > 1 else None,
+                   "note": "decode_mac on the device; N > 1: RCCL all_gather_into_tensor of PSDUs and frame records, chunk c "
+                           "overlapping decode_mac of chunk c+1 (all_gather_exposed_ms = what is left after the last decode); "
+                           "not in `value`"}
 
     # ---- sanity of the timed work: every frame must have been demodulated completely ----
     fr = frames_t.cpu().numpy().view(capi.FRAME_DTYPE).reshape(-1)
     n_complete = int(((fr["flags"] & capi.F_COMPLETE) != 0).sum())
     n_crc = int(((fr["flags"] & capi.F_CRC_OK) != 0).sum()) if want_pdus else None
+    gather_ok = None
+    if gather is not None:
+        # every rank must now hold every rank's records: compare my own rows and count the good FCS of all ranks
+        fa = gather.frames_all.cpu().numpy().view(capi.FRAME_DTYPE).reshape(-1)
+        mine = gather.frame_order()[rank]
+        gather_ok = bool(np.array_equal(fa[mine], fr))
+        n_crc_all = int(((fa["flags"] & capi.F_CRC_OK) != 0).sum())
+        pdu_leg["frames_crc_ok_all_ranks"] = n_crc_all
+        pdu_leg["gather_consistent"] = gather_ok
 
     result = None
     if rank == 0:
@@ -185,15 +306,12 @@ def main():
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate passes, FETCH_SIZE x2 per MI355X_MICROARCH.md and tools/calib_fetch.hip): collected by
         # tools/pmc.sh, committed as profiles/*_traffic.json -- a bench run cannot count PMCs itself
-        traffic = None
-        try:
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
-            with open(os.path.join(ROOT, "profiles", cands[-1])) as f:
-                tj = json.load(f)
-            traffic = tj["hbm_bytes_per_frame"] * n_frames / 1e9
-        except Exception:
-            traffic = None
+        tj = latest_profile("_traffic.json")
+        moved_per_frame = tj["hbm_bytes_per_frame"] if tj else None
+        traffic = moved_per_frame * n_frames / 1e9 if tj else None
+        floor = latest_profile("_mem_floor.json")
         achieved = bpf * n_frames / (kernel_ms_avg * 1e-3)
+        moved = moved_per_frame * n_frames / (kernel_ms_avg * 1e-3) if tj else None
         result = {
             "metric": "OFDM demod throughput (complex samples/s), 802.11a RX chain sync->LLR",
             "value": value,
@@ -209,9 +327,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE.json configs[1]: %d frames/GPU, 20 MHz QPSK-1/2, PSDU %d B (N_sym %d), "
-                            "slot %d samples, AWGN SNR %g dB, CFO +-20 ppm, device-resident"
-                            % (n_frames, PSDU_LEN, n_sym, SLOT_LEN, SNR_DB),
-                "frames_per_gpu": n_frames, "slot_len": SLOT_LEN, "encoding": "QPSK_1_2",
+                            "slot %d samples, AWGN SNR %g dB, CFO +-20 ppm, device-resident; %d TX templates (distinct "
+                            "payloads and scrambler seeds) x distinct noise and CFO per slot"
+                            % (n_frames, PSDU_LEN, n_sym, SLOT_LEN, SNR_DB, N_TEMPLATES),
+                "frames_per_gpu": n_frames, "slot_len": SLOT_LEN, "encoding": "QPSK_1_2", "tx_templates": N_TEMPLATES,
                 "outputs": "48 u8 decisions + 96 f32 LLRs per data symbol, 32 B frame record"
                            + ("; decode_mac + PSDU" if do_decode else ""),
                 "parallelism": ("frames sharded %d-way, no collective on the hot path" % world if world > 1 else "1 GPU")
@@ -221,6 +340,8 @@ def main():
             "msymbols_per_s": float(n_frames) * (n_sym + 3) * world * args.steps / elapsed / 1e6,
             "frames_complete": n_complete,
             "frames_crc_ok": n_crc,
+            "per_rank": per_rank,
+            "n1_equivalent_gsamples_per_s": per_rank[0]["gsamples_per_s"],
             "pdu_leg": pdu_leg,
             "roofline": {
                 "bound": "hbm",
@@ -229,16 +350,30 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
                 "traffic": traffic,
-                "traffic_unit": "GB per launch (PMC, profiles/*_traffic.json)",
+                "traffic_unit": "GB per launch (PMC, %s)" % (tj["_file"] if tj else "none"),
                 "kernel": "wr::demod_batch_kernel",
                 "kernel_ms": kernel_ms_avg,
                 "algorithmic_bytes_per_frame": bpf,
+                "bytes_moved_per_frame": moved_per_frame,
+                "bytes_moved_frac": moved / HBM_PEAK if moved else None,
+                "hbm_achievable": HBM_ACHIEVABLE / 1e9,
+                "frac_of_achievable": achieved / HBM_ACHIEVABLE,
+                "bytes_moved_frac_of_achievable": moved / HBM_ACHIEVABLE if moved else None,
+                "mem_floor_ms": floor.get("combined_ms") if floor else None,
+                "mem_floor_source": floor["_file"] if floor else None,
+                "frac_of_mem_floor": (floor["combined_ms"] / kernel_ms_avg) if floor and floor.get("combined_ms") else None,
             },
         }
+        if pdu_leg is not None:
+            t_pair = kernel_ms_avg + pdu_leg["decode_mac_ms"]
+            result["samples_to_pdu"] = {"demod_ms": kernel_ms_avg, "decode_mac_ms": pdu_leg["decode_mac_ms"],
+                                        "gsamples_per_s": float(n_frames) * SLOT_LEN / (t_pair * 1e-3) / 1e9,
+                                        "note": "per GPU: samples -> decoded PSDUs (demod kernel + decode_mac), device-resident"}
 
     # ---- cpu_baseline leg: the oracle on this host's cores, bounded sample of the same batch ----
     if rank == 0 and world == 1 and not args.no_cpu:      # contract: rank 0 at N=1 only
         from oracle import oracle as orc
+        march = orc.use_native_build()                    # -march=native copy built on this host when gcc is there
         cores = os.cpu_count() or 1
         prm = orc.make_params(bandwidth=BANDWIDTH, frequency=FREQUENCY, max_sym=n_sym, llr_bits=n_bpsc)
         probe = min(n_frames, 32 * cores)
@@ -260,7 +395,7 @@ def main():
         if want_pdus:       # decoded PSDUs of the same frames against the oracle's decode_mac
             n_dec = min(n_cpu, 8192)
             of = o["frames"][:n_dec].copy()
-            opsdu = orc.decode_batch(of, o["idx"][:n_dec], prm, psdu_stride=psdu_stride, n_threads=cores)
+            opsdu = orc.decode_batch(of, o["idx"][:n_dec], prm, psdu_stride=PSDU_STRIDE, n_threads=cores)
             g_psdu = psdu_t[:n_dec].cpu().numpy()
             mism += int((g_psdu[:, :PSDU_LEN] != opsdu[:, :PSDU_LEN]).sum()) + int((of["flags"] != fr[:n_dec]["flags"]).sum())
         n1 = max(64, min(n_cpu, int(rate / cores * 1.5)))          # ~1.5 s on one thread
@@ -272,11 +407,45 @@ def main():
             "value_1thread": n1 * SLOT_LEN / dt1,
             "unit": "samples/s",
             "cores": cores,
+            "cpu_model": cpu_model(),
+            "build": "gcc -O3 -march=%s -ffp-contract=off (the numerics spec forbids contraction)" % march,
             "kind": "port",
             "sample": "first %d frames of the GPU batch (%.1f s), oracle spec mode, OpenMP over frames" % (n_cpu, dt),
             "gpu_vs_cpu": value / (n_cpu * SLOT_LEN / dt),
         }
-        result["parity"] = {"frames_checked": n_cpu, "mismatching_values": mism}
+        result["parity"] = {"frames_checked": n_cpu, "mismatching_values": mism,
+                            "oracle": "parity unpinned: the reference holds no vectors for this path (DESIGN.md section 2)"}
+
+        # ---- host_path leg: the drop-in block fed the way a GNU Radio scheduler feeds it ----
+        if args.host_samples > 0:
+            from wifirx import block, grshim
+            n_host = max(1, min(n_frames, args.host_samples // SLOT_LEN))
+            xs = iq[:n_host].cpu().numpy().view(np.complex64).reshape(-1)
+            blk = block.wifi_phy_rx(bandwidth=BANDWIDTH, frequency=FREQUENCY, max_sym=n_sym, publish_carrier=False,
+                                    device=local_rank)
+            got = []
+            grshim.msg_connect(blk, "mac_out", grshim.sink_block(got.append), "in")
+            grshim.run_stream(blk, xs[:SLOT_LEN * min(n_host, 256)], chunk=8192, finish=False)     # warm-up: allocations
+            n0 = len(got)
+            t = time.perf_counter()
+            grshim.run_stream(blk, xs, chunk=8192)
+            dth = time.perf_counter() - t
+            result["host_path"] = {"gsamples_per_s": xs.size / dth / 1e9, "work_chunk_items": 8192, "samples": int(xs.size),
+                                   "pdus": len(got) - n0, "frames_in": n_host,
+                                   "note": "wifi_phy_rx.work() with pageable host chunks: PCIe copy, detection, frame kernel, "
+                                           "decode_mac, PDU construction in Python; never `value`"}
+            blk.close()
+
+        # ---- config 2, CFO = 0 variant: same frames and noise law, no carrier offset ----
+        rx.synth_slots(tx.samples, iq.data_ptr(), SLOT_LEN, n_frames, LEAD, SNR_DB, 0.0, synth_seed, cfo.data_ptr())
+        step()
+        k0 = max(2, min(args.steps, 5))
+        ms0 = sum(step() for _ in range(k0)) / k0
+        fr0 = frames_t.cpu().numpy().view(capi.FRAME_DTYPE).reshape(-1)
+        result["variants"] = {"cfo0": {"kernel_ms": ms0, "gsamples_per_s": float(n_frames) * SLOT_LEN / (ms0 * 1e-3) / 1e9,
+                                       "frac": bpf * n_frames / (ms0 * 1e-3) / HBM_PEAK,
+                                       "frames_complete": int(((fr0["flags"] & capi.F_COMPLETE) != 0).sum()),
+                                       "note": "config 2 with CFO = 0 (IRS_tranceiver.py:121 range centre), device kernel time"}}
 
     if rank == 0:
         print(json.dumps(result))
@@ -284,6 +453,69 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     rx.close()
+
+
+def run_stub(args, rank, world, dist, wdist, torch):
+    """CPU rehearsal (WIFIRX_BENCH_STUB=1, gloo): the launcher, the rank bookkeeping, the barrier / max-over-ranks timing
+    and the chunked PDU all-gather with a stand-in for the compute step.  The JSON line says so; nothing here is a
+    measurement of the product."""
+    from wifirx import capi
+    n_frames = min(args.frames, 4096)
+    frames = np.zeros(n_frames, capi.FRAME_DTYPE)
+    psdu = np.zeros((n_frames, PSDU_STRIDE), np.uint8)
+
+    def step():           # stand-in for demod + decode_mac: every frame "decodes" to a rank- and frame-dependent PSDU
+        k = np.arange(n_frames)
+        frames["flags"] = capi.F_DETECTED | capi.F_SYNC | capi.F_SIGNAL | capi.F_COMPLETE | capi.F_DECODED | capi.F_CRC_OK
+        frames["psdu_len"] = 64
+        frames["trigger"] = k
+        psdu[:, 0] = rank
+        psdu[:, 1:5] = (k[:, None] >> (8 * np.arange(4))) & 255
+        return 0.0
+
+    gather = wdist.ChunkedPduGather(n_frames, PSDU_STRIDE, args.gather_chunks, "cpu") if world > 1 else None
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ok = True
+    n_pdus = n_frames
+    if gather is not None:
+        p_t = torch.from_numpy(psdu)
+        f_t = torch.from_numpy(frames.view(np.uint8).reshape(n_frames, 32))
+        for c in range(gather.n_chunks):
+            gather.gather_chunk(c, p_t, f_t, async_op=False)
+        pdus = gather.pdus()
+        n_pdus = len(pdus)
+        for g, b in pdus:                       # global frame g = rank r, local frame j
+            r, j = divmod(g, n_frames)
+            ok &= b[0] == r and int.from_bytes(b[1:5], "little") == j and len(b) == 60
+        ok &= n_pdus == world * n_frames
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        ok = all(flags)
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (no GPU work): launcher + all-gather rehearsal", "value": 0.0, "unit": "samples/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "stub", "parallelism": "gloo, %d ranks" % world},
+                          "pdus_gathered": n_pdus, "gather_consistent": bool(ok),
+                          "gather_chunks": gather.n_chunks if gather else None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -67,7 +67,7 @@ struct wifirx_handle {
     uint8_t* s_above = nullptr;     float2* s_A = nullptr;    int64_t s_above_cap = 0;
     std::vector<PendingTrig> pending;
     std::deque<PolledFrame>  queue;
-    void*  s_trig = nullptr;  void* s_frames = nullptr;  void* s_idx = nullptr;  void* s_llr = nullptr;
+    void*  s_trig = nullptr;  void* s_frames = nullptr;  void* s_idx = nullptr;
     void*  s_car = nullptr;   void* s_psdu = nullptr;    uint32_t s_cap = 0;
     void*  s_csi = nullptr;
 };
@@ -172,7 +172,7 @@ int wifirx_destroy(wifirx_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi,
-                     h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx, h->s_llr,
+                     h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx,
                      h->s_car, h->s_psdu, h->s_csi };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->s_pack) (void)hipFree(h->s_pack);
@@ -186,6 +186,7 @@ int wifirx_destroy(wifirx_handle* h)
 int wifirx_set_param(wifirx_handle* h, int id, double value)
 {
     if (!h) return WIFIRX_EINVAL;
+    if (!std::isfinite(value)) return fail(h, WIFIRX_EINVAL, "parameter value must be finite");
     switch (id) {
     case WIFIRX_P_BANDWIDTH:
         if (!(value > 0)) return fail(h, WIFIRX_EINVAL, "bandwidth must be > 0");
@@ -199,7 +200,7 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
         h->cfg.sensitivity = (float)value;
         return WIFIRX_OK;
     case WIFIRX_P_CHAN_EST:
-        if ((int)value < WIFIRX_EQ_LS || (int)value > WIFIRX_EQ_STA)
+        if (value < WIFIRX_EQ_LS || value > WIFIRX_EQ_STA || value != std::floor(value))
             return fail(h, WIFIRX_EINVAL, "chan_est must be one of WIFIRX_EQ_LS, LMS, COMB, STA");
         h->cfg.chan_est = (int)value;
         return WIFIRX_OK;
@@ -357,23 +358,24 @@ int wifirx_time_demod(wifirx_handle* h, const float* iq_dev, uint32_t slot_len, 
     if (!iq_dev || !ms_mean || iters <= 0 || !out->on_device) return fail(h, WIFIRX_EINVAL, "device buffers and iters > 0 required");
     HIP_TRY(h, hipSetDevice(h->device));
     const wr::DemodParams prm = params_of(h);
-    hipEvent_t e0, e1;
-    HIP_TRY(h, hipEventCreate(&e0));
-    HIP_TRY(h, hipEventCreate(&e1));
+    struct Events {                       // destroyed on every exit
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    HIP_TRY(h, hipEventCreate(&ev.e0));
+    HIP_TRY(h, hipEventCreate(&ev.e1));
     double total = 0;
     for (int i = 0; i < iters; i++) {
-        HIP_TRY(h, hipEventRecord(e0, h->stream));
+        HIP_TRY(h, hipEventRecord(ev.e0, h->stream));
         HIP_TRY(h, wr_launch_demod_batch(h->stream, reinterpret_cast<const float2*>(iq_dev), slot_len, n_slots, &prm,
                                          out->frames, out->idx, out->llr, reinterpret_cast<float2*>(out->carrier),
                                          reinterpret_cast<float2*>(out->csi)));
-        HIP_TRY(h, hipEventRecord(e1, h->stream));
-        HIP_TRY(h, hipEventSynchronize(e1));
+        HIP_TRY(h, hipEventRecord(ev.e1, h->stream));
+        HIP_TRY(h, hipEventSynchronize(ev.e1));
         float ms = 0;
-        HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+        HIP_TRY(h, hipEventElapsedTime(&ms, ev.e0, ev.e1));
         total += ms;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *ms_mean = (float)(total / iters);
     return WIFIRX_OK;
 }
@@ -392,7 +394,11 @@ int wifirx_synth_slots(wifirx_handle* h, const float* templates, int templates_o
         size_t bytes = (size_t)n_templates * frame_len * sizeof(float2);
         hipError_t e = hipMalloc(&tmp, bytes);
         if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, "hipMalloc(templates)");
-        HIP_TRY(h, hipMemcpyAsync(tmp, templates, bytes, hipMemcpyHostToDevice, h->stream));
+        e = hipMemcpyAsync(tmp, templates, bytes, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(tmp);
+            return fail(h, WIFIRX_EHIP, std::string("template upload: ") + hipGetErrorString(e));
+        }
         d_t = reinterpret_cast<const float2*>(tmp);
     }
     float gain = std::sqrt(std::pow(10.0f, snr_db / 10.0f));

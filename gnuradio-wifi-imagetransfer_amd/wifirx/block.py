@@ -150,3 +150,7 @@ class wifi_phy_rx(grshim.sync_block):
 
     def stats(self):
         return self._rx.stats()
+
+    def close(self):
+        """Release the library handle (device buffers, stream)."""
+        self._rx.close()

@@ -197,7 +197,7 @@ class WifiRx:
             return dict(frames=frames, idx=idx, llr=llr, carrier=car, psdu=None, csi=csi)
         # decode needs the decisions on the device: run on device buffers, then download
         d_iq = self.alloc(iq.nbytes).upload(iq)
-        dev = self.alloc_out(n_slots, psdu_stride=psdu_stride)
+        dev = self.alloc_out(n_slots, psdu_stride=psdu_stride, want_csi=want_csi)
         try:
             self.demod_batch_dev(d_iq.ptr, slot_len, n_slots, dev)
             self.decode_batch_dev(n_slots, dev)
@@ -208,27 +208,28 @@ class WifiRx:
             self.free_out(dev)
 
     # -- batch mode, device buffers (the measured path) --
-    def alloc_out(self, n_slots, psdu_stride=0) -> dict:
+    def alloc_out(self, n_slots, psdu_stride=0, want_csi=False) -> dict:
         ms = self.cfg.max_sym
         d = dict(n_slots=n_slots, psdu_stride=psdu_stride)
+        d["csi"] = self.alloc(n_slots * 52 * 8) if want_csi else None
         d["frames"] = self.alloc(n_slots * 32)
         d["idx"] = self.alloc(n_slots * ms * 48)
         d["llr"] = self.alloc(n_slots * ms * 48 * self.cfg.llr_bits * 4) if self.cfg.llr_bits else None
         d["carrier"] = self.alloc(n_slots * ms * 48 * 8) if self.cfg.want_carrier else None
         d["psdu"] = self.alloc(n_slots * psdu_stride) if psdu_stride else None
-        for k in ("frames", "idx", "llr", "carrier", "psdu"):      # the kernels only write what a frame fills
+        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi"):      # the kernels only write what a frame fills
             if d[k] is not None and d[k].nbytes:
                 d[k].upload(np.zeros(d[k].nbytes, dtype=np.uint8))
         return d
 
     def free_out(self, dev):
-        for k in ("frames", "idx", "llr", "carrier", "psdu"):
+        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi"):
             if dev.get(k) is not None:
                 dev[k].free()
 
     def _out_struct(self, dev) -> Out:
         g = lambda k: dev[k].ptr if dev.get(k) is not None else None
-        return Out(g("frames"), g("idx"), g("llr"), g("carrier"), g("psdu"), dev.get("psdu_stride", 0), 1, None)
+        return Out(g("frames"), g("idx"), g("llr"), g("carrier"), g("psdu"), dev.get("psdu_stride", 0), 1, g("csi"))
 
     def demod_batch_dev(self, iq_ptr, slot_len, n_slots, dev):
         out = self._out_struct(dev)
@@ -248,7 +249,9 @@ class WifiRx:
         ms = self.cfg.max_sym
         r = dict(frames=dev["frames"].download(FRAME_DTYPE, n_slots),
                  idx=dev["idx"].download(np.uint8, n_slots * ms * 48).reshape(n_slots, ms, 48),
-                 llr=None, carrier=None, psdu=None)
+                 llr=None, carrier=None, psdu=None, csi=None)
+        if dev.get("csi") is not None:
+            r["csi"] = dev["csi"].download(np.complex64, n_slots * 52).reshape(n_slots, 52)
         if dev.get("llr") is not None:
             r["llr"] = dev["llr"].download(np.float32, n_slots * ms * 48 * self.cfg.llr_bits).reshape(n_slots, -1)
         if dev.get("carrier") is not None:

@@ -77,6 +77,16 @@ else:
             raise NotImplementedError
 
 
+class sink_block(basic_block if not HAVE_GNURADIO else object):
+    """Message sink with one input port ``in`` that hands every PDU (as Python) to ``fn`` -- what
+    ``blocks.message_debug`` is to a flowgraph, for the shim's harnesses (bench host_path leg, tests)."""
+
+    def __init__(self, fn):
+        basic_block.__init__(self, name="sink", in_sig=None, out_sig=None)
+        self.message_port_register_in(intern("in"))
+        self.set_msg_handler(intern("in"), lambda msg: fn(to_python(msg)))
+
+
 def msg_connect(src, sport, dst, dport):
     """``tb.msg_connect((src, sport), (dst, dport))`` for shim blocks."""
     src._out_ports[sport].append((dst, dport))

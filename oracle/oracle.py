@@ -43,15 +43,43 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def use_native_build() -> str:
+    """bench.py's cpu_baseline leg: a copy of the oracle compiled with -march=native ON THIS HOST (gcc is on the GPU box
+    too), so that the CPU baseline is not held back by the portable -march=x86-64-v3 of the shipped liboracle.so.
+    Returns the -march the loaded library was built with.  Must be called before the first lib()."""
+    global _lib
+    import tempfile
+    if _lib is not None:
+        return "x86-64-v3"
+    try:
+        out = os.path.join(tempfile.mkdtemp(prefix="wifirx_oracle_"), "liboracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC",
+                               "-I" + os.path.join(os.path.dirname(HERE), "include"), "-shared", "-o", out,
+                               os.path.join(HERE, "wifirx_oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        _load(out)
+        return "native"
+    except Exception:
+        _lib = None
+        lib()
+        return "x86-64-v3"
+
+
+def _load(path):
+    global _lib
+    _lib = C.CDLL(path)
+    _lib.orc_sync_short.restype = C.c_long
+    _lib.orc_demod_stream.restype = C.c_long
+    _lib.orc_crc32.restype = C.c_uint32
+    return _lib
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB):
             build()
-        _lib = C.CDLL(LIB)
-        _lib.orc_sync_short.restype = C.c_long
-        _lib.orc_demod_stream.restype = C.c_long
-        _lib.orc_crc32.restype = C.c_uint32
+        _load(LIB)
     return _lib
 
 

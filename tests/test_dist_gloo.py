@@ -65,3 +65,54 @@ def test_all_gather_of_pdus_world2():
     lo1, _ = wdist.shard_range(n_frames, 1, 2)
     expect = [(k, bytes(ref[k, :56])) for k in range(n_frames) if k != lo1 + 2]
     assert res[0] == expect and res[1] == expect       # every rank ends with the whole PDU stream, in frame order
+
+
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks_world2():
+    """`python bench.py --gpus 2` with no torchrun around it: the parent starts two ranks itself (before touching a
+    GPU), the ranks run the timed-loop bookkeeping and the chunked PDU all-gather over gloo with a stand-in compute
+    step (WIFIRX_BENCH_STUB=1), rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WIFIRX_BENCH_STUB="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--frames", "1000", "--gather-chunks", "3"], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                       # one JSON line, from rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["data"] == "stub"
+    assert j["gather_consistent"] is True and j["pdus_gathered"] == 2000 and j["gather_chunks"] == 3
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WIFIRX_BENCH_STUB="1", WORLD_SIZE="4", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
+
+
+def test_chunked_gather_row_order():
+    """frame_order() maps (rank, local frame) to its row of the [chunk][rank][frame] buffers, for even and ragged chunks"""
+    class G(wdist.ChunkedPduGather):
+        def __init__(self, n_local, n_chunks, world):       # layout arithmetic only: no process group
+            self.world, self.n_local = world, n_local
+            self.n_chunks = max(1, min(n_chunks, n_local))
+            self.cf = (n_local + self.n_chunks - 1) // self.n_chunks
+            self.n_chunks = (n_local + self.cf - 1) // self.cf
+    for n_local, n_chunks, world in ((12, 3, 2), (11, 3, 2), (1000, 7, 8), (5, 8, 3)):
+        g = G(n_local, n_chunks, world)
+        o = g.frame_order()
+        assert o.shape == (world, n_local) and len(np.unique(o)) == world * n_local
+        assert o.max() < g.n_chunks * world * g.cf
+        for c in range(g.n_chunks):
+            lo, hi = g.chunk_range(c)
+            for r in range(world):               # chunk c of rank r is one contiguous block of the gathered buffer
+                assert np.array_equal(o[r, lo:hi], (c * world + r) * g.cf + np.arange(hi - lo))
