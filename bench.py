@@ -425,7 +425,7 @@ def main():
                                     device=local_rank)
             got = []
             grshim.msg_connect(blk, "mac_out", grshim.sink_block(got.append), "in")
-            grshim.run_stream(blk, xs[:SLOT_LEN * min(n_host, 256)], chunk=8192, finish=False)     # warm-up: allocations
+            grshim.run_stream(blk, xs[:SLOT_LEN * min(n_host, 256)], chunk=8192)     # warm-up (allocations); stop() settles its frames
             n0 = len(got)
             t = time.perf_counter()
             grshim.run_stream(blk, xs, chunk=8192)

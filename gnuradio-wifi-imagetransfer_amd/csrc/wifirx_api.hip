@@ -70,6 +70,7 @@ struct wifirx_handle {
     void*  s_trig = nullptr;  void* s_frames = nullptr;  void* s_idx = nullptr;
     void*  s_car = nullptr;   void* s_psdu = nullptr;    uint32_t s_cap = 0;
     void*  s_csi = nullptr;
+    int    test_fail_alloc = 0, test_alloc_count = 0;      // WIFIRX_TEST_FAIL_ALLOC (allocation-failure tests)
 };
 
 namespace {
@@ -158,6 +159,7 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
     h->cfg = *cfg;
     h->device = cfg->device;
     if (const char* e = std::getenv("WIFIRX_DECODE_SMALL_MAX")) h->decode_small_max = (uint32_t)std::strtoul(e, nullptr, 10);   // tests pick the decode kernel with this
+    if (const char* e = std::getenv("WIFIRX_TEST_FAIL_ALLOC")) h->test_fail_alloc = std::atoi(e);
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(nullptr, WIFIRX_EHIP, "hipStreamCreate failed");
@@ -401,9 +403,11 @@ int wifirx_synth_slots(wifirx_handle* h, const float* templates, int templates_o
         }
         d_t = reinterpret_cast<const float2*>(tmp);
     }
-    float gain = std::sqrt(std::pow(10.0f, snr_db / 10.0f));
+    // snr_db = NaN: the noiseless channel (gain 1, no AWGN) -- what txgen.impair(snr_db=None) is on the host
+    const bool noiseless = std::isnan(snr_db);
+    float gain = noiseless ? 1.0f : std::sqrt(std::pow(10.0f, snr_db / 10.0f));
     hipError_t e = wr_launch_synth(h->stream, d_t, n_templates, frame_len, reinterpret_cast<float2*>(slots), slot_len,
-                                   n_slots, lead, gain, cfo_max, seed, cfo_out);
+                                   n_slots, lead, gain, noiseless ? 0.0f : 1.0f, cfo_max, seed, cfo_out);
     hipError_t e2 = hipStreamSynchronize(h->stream);
     if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) return fail(h, WIFIRX_EHIP, std::string("synth launch: ") + hipGetErrorString(e));

@@ -46,7 +46,7 @@ hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot
                                  float* llr, float2* carrier, float2* csi);
 hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_templates, uint32_t frame_len,
                            float2* slots, uint32_t slot_len, uint32_t n_slots, uint32_t lead, float gain,
-                           float cfo_max, uint64_t seed, float* cfo_out);
+                           float noise, float cfo_max, uint64_t seed, float* cfo_out);
 hipError_t wr_launch_decode_maxsteps(hipStream_t st, uint32_t n_slots, uint32_t max_sym,
                                      const wifirx_frame* frames, uint32_t psdu_stride, uint32_t* out);
 hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,

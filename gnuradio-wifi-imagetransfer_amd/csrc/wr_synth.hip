@@ -34,7 +34,7 @@ __device__ __forceinline__ float slot_cfo(uint32_t slot, uint64_t seed, float cf
 __global__ __launch_bounds__(256)
 void synth_kernel(const float2* __restrict__ templates, uint32_t n_templates, uint32_t frame_len,
                   float2* __restrict__ slots, uint32_t slot_len, uint32_t n_slots, uint32_t lead,
-                  float gain, float cfo_max, uint64_t seed, float* __restrict__ cfo_out)
+                  float gain, float noise, float cfo_max, uint64_t seed, float* __restrict__ cfo_out)
 {
     const uint64_t half = slot_len / 2;
     const uint64_t total = (uint64_t)n_slots * half;
@@ -50,7 +50,7 @@ void synth_kernel(const float2* __restrict__ templates, uint32_t n_templates, ui
         float s1, c1, s2, c2;
         sincosf(6.283185307179586f * u01(r.y), &s1, &c1);
         sincosf(6.283185307179586f * u01(r.w), &s2, &c2);
-        const float h = 0.70710678118654752f;
+        const float h = 0.70710678118654752f * noise;       // noise = 1 (unit-variance AWGN) or 0 (noiseless: tests)
         float4 o = make_float4(h * r1 * c1, h * r1 * s1, h * r2 * c2, h * r2 * s2);
         const float2* tp = templates + (size_t)(slot % n_templates) * frame_len;
 #pragma unroll
@@ -72,13 +72,13 @@ void synth_kernel(const float2* __restrict__ templates, uint32_t n_templates, ui
 
 extern "C" hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_templates,
                                       uint32_t frame_len, float2* slots, uint32_t slot_len, uint32_t n_slots,
-                                      uint32_t lead, float gain, float cfo_max, uint64_t seed, float* cfo_out)
+                                      uint32_t lead, float gain, float noise, float cfo_max, uint64_t seed, float* cfo_out)
 {
     uint64_t total = (uint64_t)n_slots * (slot_len / 2);
     if (total == 0) return hipSuccess;
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(wr::synth_kernel, dim3((unsigned)blocks), dim3(256), 0, st, templates, n_templates,
-                       frame_len, slots, slot_len, n_slots, lead, gain, cfo_max, seed, cfo_out);
+                       frame_len, slots, slot_len, n_slots, lead, gain, noise, cfo_max, seed, cfo_out);
     return hipGetLastError();
 }

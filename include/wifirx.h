@@ -216,7 +216,8 @@ void* wifirx_stream(wifirx_handle* h);
  * i uses template i % n_templates): slot = noise(unit variance, Philox counter RNG, `seed`) with
  * the frame scaled by sqrt(10^(snr_db/10)) and rotated by a per-slot CFO drawn uniformly from
  * +-cfo_max rad/sample, placed `lead` samples into the slot.  Writes `cfo_out[n_slots]` when
- * non-NULL.  Output `slots` is device memory of n_slots*slot_len complex64. */
+ * non-NULL.  Output `slots` is device memory of n_slots*slot_len complex64.  snr_db = NaN selects the
+ * noiseless channel (gain 1, no AWGN; the slot outside the frame is zero). */
 int  wifirx_synth_slots(wifirx_handle* h, const float* templates, int templates_on_device,
                         uint32_t n_templates, uint32_t frame_len, float* slots, uint32_t slot_len,
                         uint32_t n_slots, uint32_t lead, float snr_db, float cfo_max,

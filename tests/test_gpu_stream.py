@@ -143,3 +143,48 @@ def test_stream_csi_equals_batch_csi_and_reaches_the_pdu(orc):
     meta, blob = pdus[0]
     assert meta["csi"].shape == (52,) and np.array_equal(meta["csi"].view(np.uint64), o["csi"][0].view(np.uint64))
     assert np.array_equal(blob, psdu[0][:-4])
+
+
+def test_push_after_a_failed_allocation_recovers(orc, monkeypatch):
+    """A hipMalloc of the stream path fails once (WIFIRX_TEST_FAIL_ALLOC = which one): that push returns ENOMEM, leaves
+    the handle consistent -- no stale capacity over freed buffers -- and the stream, pushed again, delivers exactly
+    the frames of an undisturbed run."""
+    from wifirx import capi
+    x, _ = build_stream(seed=5)
+    chunk = 30000
+    rx = capi.WifiRx(max_sym=511)
+    ref = []
+    for p in range(0, x.size, chunk):
+        rx.push(x[p:p + chunk])
+        ref.append(rx.poll(cap=64, want_idx=True))
+    rx._check(capi.lib().wifirx_push(rx._h, None, 0, 0))
+    ref.append(rx.poll(cap=64, want_idx=True))
+    rx.close()
+    ref_frames = np.concatenate([g["frames"] for g in ref])
+    ref_psdu = np.concatenate([g["psdu"] for g in ref])
+    assert len(ref_frames) == 10
+    failures = 0
+    for k in range(1, 14):               # 3 sample-side buffers + 5 output buffers, and their first regrowth
+        monkeypatch.setenv("WIFIRX_TEST_FAIL_ALLOC", str(k))
+        rx = capi.WifiRx(max_sym=511)
+        got = []
+        for p in range(0, x.size, chunk):
+            piece = x[p:p + chunk]
+            try:
+                rx.push(piece)
+            except capi.WifiRxError as e:
+                assert e.code == -3 or "hipMalloc" in str(e)          # WIFIRX_ENOMEM
+                failures += 1
+                # a failure of the sample-side buffers comes before the copy: nothing was consumed, hand the piece in
+                # again; a failure of the output rows comes after it: the triggers stay pending for the next push
+                if "stream buffers" in str(e):
+                    rx.push(piece)
+            got.append(rx.poll(cap=64, want_idx=True))
+        rx._check(capi.lib().wifirx_push(rx._h, None, 0, 0))
+        got.append(rx.poll(cap=64, want_idx=True))
+        rx.close()
+        frames = np.concatenate([g["frames"] for g in got])
+        psdu = np.concatenate([g["psdu"] for g in got])
+        assert np.array_equal(frames, ref_frames), k
+        assert np.array_equal(psdu, ref_psdu), k
+    assert failures >= 8
