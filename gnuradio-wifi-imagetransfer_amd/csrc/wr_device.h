@@ -10,6 +10,7 @@
 
 #define WR_TABLE_QUAL __device__
 #define WR_WANT_T4_TABLE
+#define WR_WANT_LTS_MFMA_TABLE
 #include "wifirx_tables.h"
 
 namespace wr {

@@ -26,6 +26,9 @@
 #ifndef WR_ABLATE
 #define WR_ABLATE 0
 #endif
+#ifndef WR_DETECT_AHEAD
+#define WR_DETECT_AHEAD 4      // tiles of 64 samples whose loads detect_first issues up front
+#endif
 
 namespace wr {
 
@@ -39,18 +42,17 @@ struct DetectState {       // what a tile needs from the tile before it
 
 __device__ __forceinline__ DetectState detect_state_zero() { return { 0, 0, 0, 0, 0, 0 }; }
 
-// Processes tile [n0, n0+64).  Returns the ballot of c[n] > thr; Ar/Ai = A[n] of this lane's sample.
-__device__ __forceinline__ uint64_t detect_tile(const float2* __restrict__ x, long n_samp, long n0, float thr,
-                                                int lane, DetectState& ps, float& Ar, float& Ai)
+// Processes tile [n0, n0+64) given this lane's sample xn = x[n0 + lane] and xd = x[n0 + lane - 16] (zero outside the
+// stream).  Returns the ballot of c[n] > thr; Ar/Ai = A[n] of this lane's sample.
+__device__ __forceinline__ uint64_t detect_tile_core(c32 xn, c32 xd, long n_samp, long n0, float thr,
+                                                     int lane, DetectState& ps, float& Ar, float& Ai)
 {
     const int q = lane >> 4;
     const int l16 = (lane + 16) & 63;              // lane that holds index lane-48 (mod 64)
     const int b1 = (((q - 1) & 3) << 4) | 15;      // last lane of block m-1 / m-2 / m-3
     const int b2 = (((q - 2) & 3) << 4) | 15;
     const int b3 = (((q - 3) & 3) << 4) | 15;
-    long n = n0 + lane;
-    c32 xn = load_sample(x, n, n_samp);
-    c32 xd = load_sample(x, n - 16, n_samp);
+    const long n = n0 + lane;
     float ar = fma_(xn.im, xd.im, xn.re * xd.re);
     float ai = fma_(xn.im, xd.re, -(xn.re * xd.im));
     float pw = fma_(xn.im, xn.im, xn.re * xn.re);
@@ -85,6 +87,13 @@ __device__ __forceinline__ uint64_t detect_tile(const float2* __restrict__ x, lo
     return __ballot(above);
 }
 
+__device__ __forceinline__ uint64_t detect_tile(const float2* __restrict__ x, long n_samp, long n0, float thr,
+                                                int lane, DetectState& ps, float& Ar, float& Ai)
+{
+    const long n = n0 + lane;
+    return detect_tile_core(load_sample(x, n, n_samp), load_sample(x, n - 16, n_samp), n_samp, n0, thr, lane, ps, Ar, Ai);
+}
+
 // positions where c > thr held for min_plateau+1 consecutive samples ending there
 __device__ __forceinline__ uint64_t plateau_hits(uint64_t mask, uint64_t prev_mask, int min_plateau)
 {
@@ -94,12 +103,39 @@ __device__ __forceinline__ uint64_t plateau_hits(uint64_t mask, uint64_t prev_ma
 }
 
 // first sync_short trigger of a slot.  Returns the trigger index or -1; A_t = A[trigger].
+// The tiles are walked in order (each needs the block sums of the one before), but the samples of the first
+// WR_DETECT_AHEAD of them are requested up front by detect_load() -- for all four slots of a wave before the first
+// scan starts -- so that a frame within the usual lead-in is found without a further memory round trip.
+struct DetectAhead { c32 xn[WR_DETECT_AHEAD], xd[WR_DETECT_AHEAD]; };
+
+__device__ __forceinline__ void detect_load(const float2* __restrict__ x, long n_samp, int lane, DetectAhead& d)
+{
+#pragma unroll
+    for (int k = 0; k < WR_DETECT_AHEAD; k++) {
+        d.xn[k] = load_sample(x, 64 * k + lane, n_samp);
+        d.xd[k] = load_sample(x, 64 * k + lane - 16, n_samp);
+    }
+}
+
 __device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n_samp, float thr,
-                                            int min_plateau, int lane, c32& A_t)
+                                            int min_plateau, int lane, const DetectAhead& d, c32& A_t)
 {
     DetectState ps = detect_state_zero();
     uint64_t prev_mask = 0;
-    for (long n0 = 0; n0 < n_samp; n0 += 64) {
+#pragma unroll
+    for (int k = 0; k < WR_DETECT_AHEAD; k++) {
+        if (64 * k >= n_samp) return -1;
+        float Ar, Ai;
+        uint64_t mask = detect_tile_core(d.xn[k], d.xd[k], n_samp, 64 * k, thr, lane, ps, Ar, Ai);
+        uint64_t hit = plateau_hits(mask, prev_mask, min_plateau);
+        if (hit) {
+            int l = __builtin_ctzll(hit);
+            A_t = { bcast(Ar, l), bcast(Ai, l) };
+            return 64 * k + l;
+        }
+        prev_mask = mask;
+    }
+    for (long n0 = 64 * WR_DETECT_AHEAD; n0 < n_samp; n0 += 64) {
         float Ar, Ai;
         uint64_t mask = detect_tile(x, n_samp, n0, thr, lane, ps, Ar, Ai);
         uint64_t hit = plateau_hits(mask, prev_mask, min_plateau);
@@ -117,50 +153,54 @@ __device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n
 // batch kernel: one wave = 4 consecutive slots, WR_WAVES_PER_BLOCK waves per workgroup.
 // Preamble phase per slot with the whole wave (lane = sample / lag), then the four frames walk their
 // symbols together (wr_quad.h).
-// sync_short found trigger t in (x, n_samp): run the LTS search when enough samples were copied.
-// All arguments wave-uniform; returns the frame's flags.
-__device__ __forceinline__ uint32_t sync_after_trigger(const float2* x, long n_samp, long t, long L, float cfo_c,
-                                                       float* lds, int lane, int& fs, float& cfo_f)
-{
-    fs = 0;
-    cfo_f = 0.0f;
-    if (L < WIFIRX_SYNC_LENGTH + 63) return WIFIRX_F_DETECTED | WIFIRX_F_TRUNCATED;
-    bool ok = preamble_sync(x, n_samp, t, cfo_c, lds, lane, fs, cfo_f);
-    return ok ? (WIFIRX_F_DETECTED | WIFIRX_F_SYNC) : WIFIRX_F_DETECTED;
-}
-
 template <int EQ>
 __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ != WIFIRX_EQ_LS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
                         DemodParams prm, wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
                         float* __restrict__ llr, float2* __restrict__ carrier, float2* __restrict__ csi)
 {
-    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
+    __shared__ __attribute__((aligned(16))) float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t slot0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;
     if (slot0 >= n_slots) return;
     QuadSeed seed = quad_seed_none();
-    for (int f = 0; f < 4; f++) {
-        const uint32_t slot = slot0 + f;
-        if (slot >= n_slots) break;
-        const float2* x = iq + (size_t)slot * slot_len;
-        c32 A_t = { 0, 0 };
-        int t = detect_first(x, slot_len, prm.threshold, prm.min_plateau, lane, A_t);
-        float cfo_c = 0.0f, cfo_f = 0.0f;
-        int fs = 0;
-        long L = 0;
-        uint32_t flags = 0;
-        if (t >= 0) {
-            cfo_c = sp_atan2(A_t.im, A_t.re) / 16.0f;
-            L = (long)slot_len - (t - 16);
-            if (L > WIFIRX_MAX_SAMPLES) L = WIFIRX_MAX_SAMPLES;
-            flags = sync_after_trigger(x, slot_len, t, L, cfo_c, lds[wave], lane, fs, cfo_f);
+    // preamble phase.  Detection of the four slots with the whole wave (lane = sample), their first tiles requested
+    // together; then two slots at a time: coarse derotation of both into LDS (their loads in flight together), the LTS
+    // correlation of both on the matrix cores, the peak search per slot.
+    PreFrame pf[4];
+    {
+        DetectAhead da[4];
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const uint32_t slot = slot0 + f;
+            const bool has = slot < n_slots;                // wave-uniform
+            pf[f] = { iq + (size_t)(has ? slot : slot0) * slot_len, has ? (long)slot_len : 0l, -1, 0, 0.0f, false, has ? (long)slot : -1l };
+            detect_load(pf[f].x, pf[f].n_samp, lane, da[f]);
         }
-        if ((lane >> 4) == f) {
-            seed.x = x; seed.n_samp = slot_len; seed.t = t; seed.L = L; seed.cfo_c = cfo_c; seed.cfo_f = cfo_f;
-            seed.fs = fs; seed.flags = flags; seed.out = slot;
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            c32 A_t = { 0, 0 };
+            const int t = detect_first(pf[f].x, pf[f].n_samp, prm.threshold, prm.min_plateau, lane, da[f], A_t);
+            pf[f].t = t;
+            if (t >= 0) {
+                pf[f].cfo_c = sp_atan2(A_t.im, A_t.re) / 16.0f;
+                long L = (long)slot_len - (t - 16);
+                if (L > WIFIRX_MAX_SAMPLES) L = WIFIRX_MAX_SAMPLES;
+                pf[f].L = L;
+                pf[f].search = L >= WIFIRX_SYNC_LENGTH + 63;
+            }
         }
+    }
+    PreSamples ps[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++) preamble_load(pf[f], lane, ps[f]);
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        preamble_derotate_pair(pf[2 * p], pf[2 * p + 1], ps[2 * p], ps[2 * p + 1], lds[wave], lane);
+        __builtin_amdgcn_wave_barrier();
+        preamble_pair_finish(pf[2 * p], pf[2 * p + 1], p, lds[wave], lane, seed);
+        __builtin_amdgcn_wave_barrier();
     }
 #if WR_ABLATE == 1   // timing experiment: preamble phase only
     if ((lane & 15) == 0 && seed.out >= 0) { frames[seed.out].flags = seed.flags; frames[seed.out].frame_start = seed.fs; frames[seed.out].cfo_fine = seed.cfo_f; frames[seed.out].trigger = (int)seed.t; }
@@ -202,28 +242,36 @@ void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const Stream
                          wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
                          float* __restrict__ llr, float2* __restrict__ carrier, float2* __restrict__ csi)
 {
-    __shared__ float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
+    __shared__ __attribute__((aligned(16))) float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t k0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;
     if (k0 >= n_trig) return;
     QuadSeed seed = quad_seed_none();
+    PreFrame pf[4];
+    PreSamples ps[4];
+#pragma unroll
     for (int f = 0; f < 4; f++) {
         const uint32_t k = k0 + f;
-        if (k >= n_trig) break;
-        const StreamTrig tg = trig[k];
-        float cfo_c = tg.cfo;              // carried over from an earlier push of the same stream
-        if (!tg.pad) {
-            const float2 At = A[tg.pos];
-            cfo_c = sp_atan2(At.y, At.x) / 16.0f;
+        pf[f] = { x, 0, -1, 0, 0.0f, false, -1 };
+        if (k < n_trig) {                               // wave-uniform
+            const StreamTrig tg = trig[k];
+            float cfo_c = tg.cfo;              // carried over from an earlier push of the same stream
+            if (!tg.pad) {
+                const float2 At = A[tg.pos];
+                cfo_c = sp_atan2(At.y, At.x) / 16.0f;
+            }
+            pf[f].n_samp = n_samp; pf[f].t = tg.pos; pf[f].L = tg.usable; pf[f].cfo_c = cfo_c; pf[f].out = k;
+            pf[f].search = tg.usable >= WIFIRX_SYNC_LENGTH + 63;
         }
-        float cfo_f;
-        int fs;
-        uint32_t flags = sync_after_trigger(x, n_samp, tg.pos, tg.usable, cfo_c, lds[wave], lane, fs, cfo_f);
-        if ((lane >> 4) == f) {
-            seed.x = x; seed.n_samp = n_samp; seed.t = tg.pos; seed.L = tg.usable; seed.cfo_c = cfo_c; seed.cfo_f = cfo_f;
-            seed.fs = fs; seed.flags = flags; seed.out = k;
-        }
+        preamble_load(pf[f], lane, ps[f]);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        preamble_derotate_pair(pf[2 * p], pf[2 * p + 1], ps[2 * p], ps[2 * p + 1], lds[wave], lane);
+        __builtin_amdgcn_wave_barrier();
+        preamble_pair_finish(pf[2 * p], pf[2 * p + 1], p, lds[wave], lane, seed);
+        __builtin_amdgcn_wave_barrier();
     }
     frames_quad<EQ>(seed, prm, lds[wave], lane, frames, idx, llr, carrier, csi);
 }

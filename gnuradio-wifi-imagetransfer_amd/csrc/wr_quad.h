@@ -133,54 +133,125 @@ __device__ __forceinline__ bool parse_signal(uint32_t bits, int& enc, int& len)
 }
 
 // ---------------------------------------------------------------------------------------------
-// a2 copy + a3: sync_short's first 383 copied samples, LTS correlation, frame start, fine CFO.
-// lane <-> sample / lag; all results wave-uniform.  Returns false when no LTS pair was found.
-__device__ __forceinline__ bool preamble_sync(const float2* __restrict__ x, long n_samp, long t, float cfo_c,
-                                              float* ylds, int lane, int& fs, float& cfo_f)
+// a2 copy + a3: sync_short's first 384 copied samples, LTS correlation, frame start, fine CFO -- for TWO frames at a
+// time ("pair"): their derotated samples sit side by side in LDS and the 2 x 320 x 64 complex correlation runs on the
+// f32 matrix cores (spec rule 6), off the vector ALU that bounds this kernel.
+//
+// LDS: frame e (0/1) of the pair at floats [768 e, 768 e + 768): y[m] = (re, im) interleaved, m = 0..383.
+#define WR_PRE_FRAME_FLOATS 768
+
+typedef float wr_f4 __attribute__((ext_vector_type(4)));
+
+// One frame before the correlation: what sync_short found, and whether the LTS search can run.
+struct PreFrame {
+    const float2* x;    // always a readable pointer
+    long  n_samp;       // 0: no such slot
+    long  t, L;         // trigger (-1: none), usable copied samples
+    float cfo_c;
+    bool  search;       // enough copied samples for the LTS search
+    long  out;          // record / output row, -1: none
+};
+
+// Coarse derotation, y[m] = x[t - 16 + m] exp(-j float(cfo_c m)), m = 0..383 (lane <-> sample, six passes).
+// The samples are requested by preamble_load() -- for all frames of a wave together, before the first of them is
+// needed --, rotated and written to LDS pair by pair by preamble_derotate_pair().  A frame without a search loads
+// nothing (its LDS rows are never looked at).
+struct PreSamples { c32 xs[6]; };
+
+__device__ __forceinline__ void preamble_load(const PreFrame& f, int lane, PreSamples& ps)
+{
+    const long ns = f.search ? f.n_samp : 0;
+#pragma unroll
+    for (int pass = 0; pass < 6; pass++) ps.xs[pass] = load_sample(f.x, f.t - 16 + (pass * 64 + lane), ns);
+}
+
+__device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const PreFrame& f1, const PreSamples& s0,
+                                                       const PreSamples& s1, float* ylds, int lane)
 {
 #pragma unroll
-    for (int pass = 0; pass < 6; pass++) {
-        int m = pass * 64 + lane;
-        c32 xs = load_sample(x, t - 16 + m, n_samp);
-        float s, c;
-        sp_sincos(-cfo_c * (float)m, s, c);
-        c32 y = sp_rot(xs, s, c);
-        ylds[2 * m] = y.re;
-        ylds[2 * m + 1] = y.im;
-    }
-    __builtin_amdgcn_wave_barrier();
-    c32   corr[5];
-    float mag[5];
+    for (int e = 0; e < 2; e++) {
+        const PreFrame& f = e ? f1 : f0;
+        const PreSamples& ps = e ? s1 : s0;
+        if (!f.search) continue;                            // wave-uniform
 #pragma unroll
-    for (int pass = 0; pass < 5; pass++) {
-        int i = pass * 64 + lane;
-        float ar = 0.0f, ai = 0.0f;
-#pragma unroll 8
-        for (int k = 0; k < 64; k++) {
-            float lr = WR_LTS_TIME[2 * k], li = WR_LTS_TIME[2 * k + 1];
-            float yr = ylds[2 * (i + k)], yi = ylds[2 * (i + k) + 1];
-            ar = fma_(lr, yr, ar);
-            ar = fma_(li, yi, ar);
-            ai = fma_(lr, yi, ai);
-            ai = fma_(-li, yr, ai);
+        for (int pass = 0; pass < 6; pass++) {
+            const int m = pass * 64 + lane;
+            float s, c;
+            sp_sincos(-f.cfo_c * (float)m, s, c);
+            const c32 y = sp_rot(ps.xs[pass], s, c);
+            *reinterpret_cast<float2*>(ylds + WR_PRE_FRAME_FLOATS * e + 2 * m) = make_float2(y.re, y.im);
         }
-        corr[pass] = { ar, ai };
-        mag[pass] = fma_(ai, ai, ar * ar);
     }
-    __builtin_amdgcn_wave_barrier();
-    // The four largest |corr|^2 in turn, lowest lag first among equal values.  |corr|^2 >= +0, so its bit pattern
-    // orders like a signed integer; NaN and already-taken entries are -1 ("invalid").  Per round: one integer
-    // max over the wave (DPP inside the rows, the four row results through SGPRs), then the first lag that holds it.
-    int km[5];
+}
+
+// corr[i] = sum_k conj(lts[k]) y[i + k] for the 320 lags of both frames of the pair, as a GEMM on v_mfma_f32_16x16x4_f32
+// (bit for bit a k-ordered fmaf chain: tools/mfma_f32_probe.hip).  Lags in blocks of 8, i = 8 a + b:
+//   M: 80 rows (frame e, block a) = 5 tiles of 16;   the row of (e, a) is the 144 contiguous floats from sample 8a on;
+//   N: 16 columns = (b, real part) b = 0..7, then (b, imaginary part);      K: 144 = 36 instructions, 4 floats each.
+// Instruction 4 j + s' takes the floats phi = 16 j + 4 kk + s' (kk = lane >> 4 = its k index): one ds_read_b128 per
+// lane, tile and j feeds four instructions; the matching B values come as one 16-byte load from WR_LTS_MFMA_B.
+// Row r' = 4 q + rho of a tile (q = lane >> 4 of the result lane, rho = result register) stands for block
+//   a_local = 8 (rho >> 1) + 2 q + (rho & 1),
+// tiles 0, 1 = frame 0 blocks 0..31; tile 2 = frame 0 blocks 32..39 (rho 0, 1) and frame 1 blocks 0..7 (rho 2, 3);
+// tiles 3, 4 = frame 1 blocks 8..39 -- so that result register n of a frame (n = 0..9 in that order) holds, on the
+// lanes with (lane & 8) == 0, the lags 64 (n >> 1) + 8 (n & 1) + lane: a frame's lags split by register, never by lane.
+__device__ __forceinline__ void lts_corr_pair(const float* ylds, int lane, wr_f4 (&acc)[5])
+{
+    const int rp = lane & 15, kk = lane >> 4;
+    const int al = 8 * ((rp & 3) >> 1) + 2 * (rp >> 2) + (rp & 1);
+    const int e2 = (rp & 3) >> 1;                    // tile 2: which frame this row belongs to
+    const float* arow[5];
+    arow[0] = ylds + 16 * al + 4 * kk;
+    arow[1] = ylds + 16 * (16 + al) + 4 * kk;
+    arow[2] = ylds + (e2 ? WR_PRE_FRAME_FLOATS + 16 * (al & 7) : 16 * (32 + (al & 7))) + 4 * kk;
+    arow[3] = ylds + WR_PRE_FRAME_FLOATS + 16 * (8 + al) + 4 * kk;
+    arow[4] = ylds + WR_PRE_FRAME_FLOATS + 16 * (24 + al) + 4 * kk;
+    const float4* __restrict__ bt = reinterpret_cast<const float4*>(WR_LTS_MFMA_B) + lane;
 #pragma unroll
-    for (int pass = 0; pass < 5; pass++) km[pass] = (mag[pass] >= 0.0f) ? (int)__float_as_uint(mag[pass]) : -1;
+    for (int t = 0; t < 5; t++) acc[t] = wr_f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const float4 bq = bt[64 * j];
+        float4 aq[5];
+#pragma unroll
+        for (int t = 0; t < 5; t++) aq[t] = *reinterpret_cast<const float4*>(arow[t] + 16 * j);
+        const float bs[4] = { bq.x, bq.y, bq.z, bq.w };
+#pragma unroll
+        for (int sp = 0; sp < 4; sp++) {
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const float as = sp == 0 ? aq[t].x : sp == 1 ? aq[t].y : sp == 2 ? aq[t].z : aq[t].w;
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bs[sp], acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// Frame start and fine CFO of one frame from its 320 correlation values: cr[n] = result register n of the frame (real
+// parts on the lanes with (lane & 8) == 0, imaginary parts eight lanes further up).  All results wave-uniform.
+// Returns false when no LTS pair was found.
+__device__ __forceinline__ bool lts_peaks(const float (&cr)[10], int lane, int& fs, float& cfo_f)
+{
+    // The four largest |corr|^2 in turn, lowest lag first among equal values.  |corr|^2 >= +0, so its bit pattern
+    // orders like a signed integer; NaN, already-taken entries and the lanes that hold imaginary parts are -1
+    // ("invalid").  Per round: one integer max over the wave (DPP inside the rows, the four row results through
+    // SGPRs), then the lowest lag that holds it (per register the first lane of a ballot; lag = base + lane).
+    float ci[10];
+    int km[10];
+    const bool holds_re = (lane & 8) == 0;
+#pragma unroll
+    for (int n = 0; n < 10; n++) {
+        ci[n] = dpp_zero<0x108>(cr[n]);                         // row_shl:8: the imaginary part from lane + 8
+        const float mag = fma_(ci[n], ci[n], cr[n] * cr[n]);
+        km[n] = (holds_re && mag >= 0.0f) ? (int)__float_as_uint(mag) : -1;
+    }
     int top_off[4];
     c32 top_val[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int m = km[0];
 #pragma unroll
-        for (int pass = 1; pass < 5; pass++) m = km[pass] > m ? km[pass] : m;
+        for (int n = 1; n < 10; n++) m = km[n] > m ? km[n] : m;
         m = row_max16(m);
         const int m0 = __builtin_amdgcn_readlane(m, 15), m1 = __builtin_amdgcn_readlane(m, 31);
         const int m2 = __builtin_amdgcn_readlane(m, 47), m3 = __builtin_amdgcn_readlane(m, 63);
@@ -189,17 +260,19 @@ __device__ __forceinline__ bool preamble_sync(const float2* __restrict__ x, long
         int w = -1;
         c32 val = { 0.0f, 0.0f };
         if (best >= 0) {
+            w = 0x7fffffff;
 #pragma unroll
-            for (int pass = 4; pass >= 0; pass--) {
-                const uint64_t hit = __ballot(km[pass] == best);
-                if (hit) w = pass * 64 + (int)__builtin_ctzll(hit);
+            for (int n = 0; n < 10; n++) {
+                const uint64_t hit = __ballot(km[n] == best);
+                const int cand = 64 * (n >> 1) + 8 * (n & 1) + (int)__builtin_ctzll(hit | (1ull << 63));
+                if (hit) w = cand < w ? cand : w;
             }
-            const int wl = w & 63, wp = w >> 6;
+            const int wn = ((w >> 6) << 1) | ((w >> 3) & 1), wl = w & 0x37;
 #pragma unroll
-            for (int pass = 0; pass < 5; pass++) {
-                if (pass == wp) {
-                    val = bcast(corr[pass], wl);
-                    if (lane == wl) km[pass] = -1;
+            for (int n = 0; n < 10; n++) {
+                if (n == wn) {
+                    val = { bcast(cr[n], wl), bcast(ci[n], wl) };
+                    if (lane == wl) km[n] = -1;
                 }
             }
         }
@@ -249,6 +322,44 @@ __device__ __forceinline__ QuadSeed quad_seed_none()
     QuadSeed q;
     q.x = nullptr; q.n_samp = 0; q.t = -1; q.L = 0; q.cfo_c = 0.0f; q.cfo_f = 0.0f; q.fs = 0; q.flags = 0; q.out = -1;
     return q;
+}
+
+// The LTS search of a pair whose frames were derotated into `lds`, and the seeds of rows 2 p + e of the wave.
+__device__ __forceinline__ void preamble_pair_finish(const PreFrame& f0, const PreFrame& f1, int p, const float* lds, int lane, QuadSeed& seed)
+{
+    const PreFrame pf[2] = { f0, f1 };
+    wr_f4 acc[5];
+    const bool any = pf[0].search || pf[1].search;         // wave-uniform
+    if (any) lts_corr_pair(lds, lane, acc);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        if (pf[e].out < 0) continue;
+        int fs = 0;
+        float cfo_f = 0.0f;
+        uint32_t flags = 0;
+        if (pf[e].t >= 0) {
+            flags = WIFIRX_F_DETECTED | WIFIRX_F_TRUNCATED;
+            if (pf[e].search) {
+                float cr[10];
+                if (e == 0) {
+#pragma unroll
+                    for (int n = 0; n < 8; n++) cr[n] = acc[n >> 2][n & 3];
+                    cr[8] = acc[2][0]; cr[9] = acc[2][1];
+                } else {
+                    cr[0] = acc[2][2]; cr[1] = acc[2][3];
+#pragma unroll
+                    for (int n = 2; n < 10; n++) cr[n] = acc[3 + ((n - 2) >> 2)][(n - 2) & 3];
+                }
+                const bool ok = lts_peaks(cr, lane, fs, cfo_f);
+                flags = ok ? (WIFIRX_F_DETECTED | WIFIRX_F_SYNC) : WIFIRX_F_DETECTED;
+                if (!ok) { fs = 0; cfo_f = 0.0f; }
+            }
+        }
+        if ((lane >> 4) == 2 * p + e) {
+            seed.x = pf[e].x; seed.n_samp = pf[e].n_samp; seed.t = pf[e].t; seed.L = pf[e].L; seed.cfo_c = pf[e].cfo_c;
+            seed.cfo_f = cfo_f; seed.fs = fs; seed.flags = flags; seed.out = pf[e].out;
+        }
+    }
 }
 
 // in-register 4-point DIF butterfly (spec section 4.4)

@@ -585,9 +585,10 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     fr->psdu_len = 0; fr->encoding = 0; fr->n_bpsc = 0; fr->n_sym = 0; fr->n_sym_out = 0;
     if (L < WIFIRX_SYNC_LENGTH + 63) { fr->flags |= WIFIRX_F_TRUNCATED; return; }  /* not enough samples for the LTS search */
 
-    /* -- sync_short COPY: coarse derotation of the first 383 samples -- */
-    c32 y[WIFIRX_SYNC_LENGTH + 63];
-    for (int m = 0; m < WIFIRX_SYNC_LENGTH + 63; m++) {
+    /* -- sync_short COPY: coarse derotation of the first 383 samples (a 384th is formed too: the spec's correlation
+     *    multiplies it by zero coefficients, DESIGN.md section 4 rule 6) -- */
+    c32 y[WIFIRX_SYNC_LENGTH + 64];
+    for (int m = 0; m < WIFIRX_SYNC_LENGTH + 64; m++) {
         c32 xs = x_at(x, n_samp, t - 16 + m);
         float ang = -cfo_c * (float)m;
         float s, c;
@@ -600,14 +601,27 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     float mag[WIFIRX_SYNC_LENGTH];
     for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) {
         if (spec) {
+            /* Spec rule 6: lag i = 8a + b reads the 144 floats (72 samples, re/im interleaved) from sample 8a on; float
+             * phi = 2m + part meets tap k = m - b (coefficient 0 outside 0..63).  Both sums are ONE fmaf chain each over
+             * the floats in the order j = 0..8, s' = 0..3, kk = 0..3 of phi = 16 j + 4 kk + s' -- the order in which a
+             * chain of 36 4-deep matrix instructions accumulates them.  conj(l) y: real part lr yr + li yi, imaginary part
+             * lr yi - li yr; -li is formed as 0 - li (no negative zero among the coefficients). */
+            const float* A = &y[8 * (i >> 3)].re;
+            const int b = i & 7;
             float ar = 0.0f, ai = 0.0f;
-            for (int k = 0; k < 64; k++) {
-                float lr = WR_LTS_TIME[2 * k], li = WR_LTS_TIME[2 * k + 1];
-                ar = fmaf(lr, y[i + k].re, ar);
-                ar = fmaf(li, y[i + k].im, ar);
-                ai = fmaf(lr, y[i + k].im, ai);
-                ai = fmaf(-li, y[i + k].re, ai);
-            }
+            for (int j = 0; j < 9; j++)
+                for (int sp = 0; sp < 4; sp++)
+                    for (int kk = 0; kk < 4; kk++) {
+                        const int phi = 16 * j + 4 * kk + sp, m = phi >> 1, part = phi & 1, k = m - b;
+                        float cr = 0.0f, ci = 0.0f;
+                        if (k >= 0 && k < 64) {
+                            const float lr = WR_LTS_TIME[2 * k], li = WR_LTS_TIME[2 * k + 1];
+                            cr = part ? li : lr;
+                            ci = part ? lr : 0.0f - li;
+                        }
+                        ar = fmaf(A[phi], cr, ar);
+                        ai = fmaf(A[phi], ci, ai);
+                    }
             corr[i].re = ar; corr[i].im = ai;
             mag[i] = fmaf(ai, ai, ar * ar);
         } else {
