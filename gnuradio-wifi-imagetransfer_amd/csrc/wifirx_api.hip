@@ -23,6 +23,7 @@ struct PolledFrame {
     std::vector<uint8_t>  idx;
     std::vector<float>    carrier;
     float                 csi[104];
+    float                 stats[4];
 };
 
 struct PendingTrig {
@@ -46,6 +47,7 @@ struct wifirx_handle {
     void*  stage_car = nullptr;     size_t stage_car_bytes = 0;
     void*  stage_psdu = nullptr;    size_t stage_psdu_bytes = 0;
     void*  stage_csi = nullptr;     size_t stage_csi_bytes = 0;
+    void*  stage_stats = nullptr;   size_t stage_stats_bytes = 0;
 
     // decode workspace
     void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;
@@ -70,6 +72,7 @@ struct wifirx_handle {
     void*  s_trig = nullptr;  void* s_frames = nullptr;  void* s_idx = nullptr;
     void*  s_car = nullptr;   void* s_psdu = nullptr;    uint32_t s_cap = 0;
     void*  s_csi = nullptr;
+    void*  s_stats = nullptr;
     int    test_fail_alloc = 0, test_alloc_count = 0;      // WIFIRX_TEST_FAIL_ALLOC (allocation-failure tests)
 };
 
@@ -173,7 +176,7 @@ int wifirx_destroy(wifirx_handle* h)
     if (!h) return WIFIRX_EINVAL;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi,
+    void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi, h->stage_stats, h->s_stats,
                      h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx,
                      h->s_car, h->s_psdu, h->s_csi };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -309,6 +312,7 @@ int wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device, uint
     float*   d_llr = out->llr;
     float2*  d_car = reinterpret_cast<float2*>(out->carrier);
     float2*  d_csi = reinterpret_cast<float2*>(out->csi);
+    float4*  d_stats = reinterpret_cast<float4*>(out->sym_stats);
     if (!out->on_device) {
         if ((rc = ensure(h, &h->stage_frames, &h->stage_frames_bytes, n_slots * sizeof(wifirx_frame)))) return rc;
         d_fr = reinterpret_cast<wifirx_frame*>(h->stage_frames);
@@ -332,8 +336,13 @@ int wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device, uint
             d_csi = reinterpret_cast<float2*>(h->stage_csi);
             HIP_TRY(h, hipMemsetAsync(d_csi, 0, (size_t)n_slots * 52 * sizeof(float2), h->stream));
         }
+        if (out->sym_stats) {
+            if ((rc = ensure(h, &h->stage_stats, &h->stage_stats_bytes, (size_t)n_slots * sizeof(float4)))) return rc;
+            d_stats = reinterpret_cast<float4*>(h->stage_stats);
+        }
     }
-    HIP_TRY(h, wr_launch_demod_batch(h->stream, d_iq, slot_len, n_slots, &prm, d_fr, d_idx, d_llr, d_car, d_csi));
+    const wr::DemodOut dout = { d_fr, d_idx, d_llr, d_car, d_csi, d_stats };
+    HIP_TRY(h, wr_launch_demod_batch(h->stream, d_iq, slot_len, n_slots, &prm, &dout));
     h->stats.samples_in += n_iq;
     if (!out->on_device) {
         HIP_TRY(h, hipMemcpyAsync(out->frames, d_fr, n_slots * sizeof(wifirx_frame), hipMemcpyDeviceToHost, h->stream));
@@ -341,6 +350,7 @@ int wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device, uint
         if (out->llr) HIP_TRY(h, hipMemcpyAsync(out->llr, d_llr, idx_n * h->cfg.llr_bits * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         if (out->carrier) HIP_TRY(h, hipMemcpyAsync(out->carrier, d_car, idx_n * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
         if (out->csi) HIP_TRY(h, hipMemcpyAsync(out->csi, d_csi, (size_t)n_slots * 52 * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
+        if (out->sym_stats) HIP_TRY(h, hipMemcpyAsync(out->sym_stats, d_stats, (size_t)n_slots * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         for (uint32_t i = 0; i < n_slots; i++) {
             uint32_t f = out->frames[i].flags;
@@ -369,9 +379,9 @@ int wifirx_time_demod(wifirx_handle* h, const float* iq_dev, uint32_t slot_len, 
     double total = 0;
     for (int i = 0; i < iters; i++) {
         HIP_TRY(h, hipEventRecord(ev.e0, h->stream));
-        HIP_TRY(h, wr_launch_demod_batch(h->stream, reinterpret_cast<const float2*>(iq_dev), slot_len, n_slots, &prm,
-                                         out->frames, out->idx, out->llr, reinterpret_cast<float2*>(out->carrier),
-                                         reinterpret_cast<float2*>(out->csi)));
+        const wr::DemodOut dout = { out->frames, out->idx, out->llr, reinterpret_cast<float2*>(out->carrier),
+                                    reinterpret_cast<float2*>(out->csi), reinterpret_cast<float4*>(out->sym_stats) };
+        HIP_TRY(h, wr_launch_demod_batch(h->stream, reinterpret_cast<const float2*>(iq_dev), slot_len, n_slots, &prm, &dout));
         HIP_TRY(h, hipEventRecord(ev.e1, h->stream));
         HIP_TRY(h, hipEventSynchronize(ev.e1));
         float ms = 0;

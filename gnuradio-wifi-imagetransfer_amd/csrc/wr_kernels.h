@@ -30,6 +30,16 @@ struct DemodParams {
     int32_t  llr_csi;       // 1: LLRs weighted by |H|^2 (WIFIRX_P_LLR_CSI)
 };
 
+// device output rows of the demod kernels (null = not produced); row r of every array belongs to frame r
+struct DemodOut {
+    wifirx_frame* frames;
+    uint8_t*      idx;
+    float*        llr;
+    float2*       carrier;
+    float2*       csi;
+    float4*       sym_stats;    // per frame: sum |y|, sum |y|^2, sum |y|^4 over its equalised data symbols, 0
+};
+
 // one detected frame of a continuous stream (stream mode)
 struct StreamTrig {
     int64_t pos;        // trigger index in the stream buffer
@@ -42,8 +52,7 @@ struct StreamTrig {
 
 extern "C" {
 hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot_len, uint32_t n_slots,
-                                 const wr::DemodParams* prm, wifirx_frame* frames, uint8_t* idx,
-                                 float* llr, float2* carrier, float2* csi);
+                                 const wr::DemodParams* prm, const wr::DemodOut* out);
 hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_templates, uint32_t frame_len,
                            float2* slots, uint32_t slot_len, uint32_t n_slots, uint32_t lead, float gain,
                            float noise, float cfo_max, uint64_t seed, float* cfo_out);
@@ -59,6 +68,5 @@ hipError_t wr_launch_decode_small(hipStream_t st, uint32_t n_slots, uint32_t max
 hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_samp, int64_t tile0,
                                    int64_t n_tiles, float thr, uint64_t* masks, float2* A);
 hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
-                                  uint32_t n_trig, const wr::DemodParams* prm, const float2* A,
-                                  wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier, float2* csi);
+                                  uint32_t n_trig, const wr::DemodParams* prm, const float2* A, const wr::DemodOut* out);
 }

@@ -156,8 +156,7 @@ __device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n
 template <int EQ>
 __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ != WIFIRX_EQ_LS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
-                        DemodParams prm, wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
-                        float* __restrict__ llr, float2* __restrict__ carrier, float2* __restrict__ csi)
+                        DemodParams prm, DemodOut out)
 {
     __shared__ __attribute__((aligned(16))) float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
     const int lane = threadIdx.x & 63;
@@ -203,10 +202,10 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
         __builtin_amdgcn_wave_barrier();
     }
 #if WR_ABLATE == 1   // timing experiment: preamble phase only
-    if ((lane & 15) == 0 && seed.out >= 0) { frames[seed.out].flags = seed.flags; frames[seed.out].frame_start = seed.fs; frames[seed.out].cfo_fine = seed.cfo_f; frames[seed.out].trigger = (int)seed.t; }
+    if ((lane & 15) == 0 && seed.out >= 0) { wifirx_frame* frames = out.frames; frames[seed.out].flags = seed.flags; frames[seed.out].frame_start = seed.fs; frames[seed.out].cfo_fine = seed.cfo_f; frames[seed.out].trigger = (int)seed.t; }
     return;
 #endif
-    frames_quad<EQ>(seed, prm, lds[wave], lane, frames, idx, llr, carrier, csi);
+    frames_quad<EQ>(seed, prm, lds[wave], lane, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -238,9 +237,7 @@ void stream_detect_kernel(const float2* __restrict__ x, long n_samp, long tile0,
 template <int EQ>
 __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ != WIFIRX_EQ_LS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
 void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const StreamTrig* __restrict__ trig,
-                         uint32_t n_trig, DemodParams prm, const float2* __restrict__ A,
-                         wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx,
-                         float* __restrict__ llr, float2* __restrict__ carrier, float2* __restrict__ csi)
+                         uint32_t n_trig, DemodParams prm, const float2* __restrict__ A, DemodOut out)
 {
     __shared__ __attribute__((aligned(16))) float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
     const int lane = threadIdx.x & 63;
@@ -273,22 +270,21 @@ void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const Stream
         preamble_pair_finish(pf[2 * p], pf[2 * p + 1], p, lds[wave], lane, seed);
         __builtin_amdgcn_wave_barrier();
     }
-    frames_quad<EQ>(seed, prm, lds[wave], lane, frames, idx, llr, carrier, csi);
+    frames_quad<EQ>(seed, prm, lds[wave], lane, out);
 }
 
 }  // namespace wr
 
 extern "C" hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot_len,
-                                            uint32_t n_slots, const wr::DemodParams* prm,
-                                            wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier, float2* csi)
+                                            uint32_t n_slots, const wr::DemodParams* prm, const wr::DemodOut* out)
 {
     if (n_slots == 0) return hipSuccess;
     dim3 grid((n_slots + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
     switch (prm->chan_est) {
-    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi); break;
-    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi); break;
-    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi); break;
-    default:             hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, frames, idx, llr, carrier, csi); break;
+    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out); break;
+    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out); break;
+    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out); break;
+    default:             hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out); break;
     }
     return hipGetLastError();
 }
@@ -304,16 +300,15 @@ extern "C" hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, i
 }
 
 extern "C" hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
-                                             uint32_t n_trig, const wr::DemodParams* prm, const float2* A,
-                                             wifirx_frame* frames, uint8_t* idx, float* llr, float2* carrier, float2* csi)
+                                             uint32_t n_trig, const wr::DemodParams* prm, const float2* A, const wr::DemodOut* out)
 {
     if (n_trig == 0) return hipSuccess;
     dim3 grid((n_trig + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
     switch (prm->chan_est) {
-    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi); break;
-    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi); break;
-    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi); break;
-    default:             hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, frames, idx, llr, carrier, csi); break;
+    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, *out); break;
+    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, *out); break;
+    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, *out); break;
+    default:             hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, *out); break;
     }
     return hipGetLastError();
 }

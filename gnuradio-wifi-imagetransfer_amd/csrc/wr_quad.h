@@ -25,7 +25,8 @@ namespace wr {
 #define WR_QLDS_TW      (WR_QLDS_H + 512)              // 6 x 16 float2: stage-1/2 twiddles by row lane
 #define WR_QLDS_PREV    (WR_QLDS_TW + 192)             // 4 rows x 4 float2: pilots of the previous symbol
 #define WR_QLDS_W       (WR_QLDS_PREV + 32)            // 4 x 64 floats: |H|^2 of the LS estimate (LLR weight, lane-private slots)
-#define WR_QLDS_FLOATS  (WR_QLDS_W + 256)            // per wave: max(383 preamble samples, 4 rows x 64 values) complex
+#define WR_QLDS_STAT    (WR_QLDS_W + 256)            // 4 rows x 4 floats: running sums of |y|, |y|^2, |y|^4 (sym_stats output)
+#define WR_QLDS_FLOATS  (WR_QLDS_STAT + 16)          // per wave; the preamble phase uses the first 1536 floats for two frames' samples
 #define WR_QLDS_DH      (WR_QLDS_FLOATS)             // COMB only: 4 x 64 float2, the running estimate d_H
 #define WR_QLDS_FLOATS_EQ(EQ) (WR_QLDS_FLOATS + ((EQ) == WIFIRX_EQ_COMB ? 512 : 0))
 
@@ -463,10 +464,14 @@ __device__ __forceinline__ c32 point_of(unsigned idx, int n_bpsc)
 // EQ = WIFIRX_EQ_STA:  spectral-temporal averaging of the per-bin estimates X/point.
 template <int EQ>
 __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodParams& prm, float* qlds, int lane,
-                                            wifirx_frame* __restrict__ frames, uint8_t* __restrict__ idx_all,
-                                            float* __restrict__ llr_all, float2* __restrict__ car_all,
-                                            float2* __restrict__ csi_all)
+                                            const DemodOut& dout)
 {
+    wifirx_frame* __restrict__ frames = dout.frames;
+    uint8_t* __restrict__ idx_all = dout.idx;
+    float* __restrict__ llr_all = dout.llr;
+    float2* __restrict__ car_all = dout.carrier;
+    float2* __restrict__ csi_all = dout.csi;
+    float4* __restrict__ stat_all = dout.sym_stats;
     constexpr bool LMS = EQ == WIFIRX_EQ_LMS, COMB = EQ == WIFIRX_EQ_COMB, STA = EQ == WIFIRX_EQ_STA;
     constexpr bool DIV = EQ != WIFIRX_EQ_LS;         // Y = X / H by division (LS multiplies by G = conj(H)/|H|^2)
     const int row = lane >> 4, r = lane & 15;
@@ -521,6 +526,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             twl[(j + 2) * 16 + r] = make_float2(WR_TWIDDLE64[2 * e2], WR_TWIDDLE64[2 * e2 + 1]);
         }
     }
+    float* stl = qlds + WR_QLDS_STAT + 4 * row;                           // the row's running sums (lane r = 0 updates them)
+    if (stat_all != nullptr && r < 4) stl[r] = 0.0f;
     float2* Hl = reinterpret_cast<float2*>(qlds + WR_QLDS_H) + lane;      // element j at Hl[64 j]
     float2* pvl = reinterpret_cast<float2*>(qlds + WR_QLDS_PREV) + 4 * row;
     float* Wl = qlds + WR_QLDS_W + lane;                                  // element j at Wl[64 j]
@@ -874,6 +881,21 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                     WR_STORE(6, act && n_bpsc == 6)
                 }
 #undef WR_STORE
+                if (stat_all != nullptr) {
+                    // moments of the equalised points for the probe_mpsk_snr_est consumer (IRS_AP.py:275,312): per lane
+                    // the data bins r + 16 j in ascending j (others 0), the row by the spec's xor tree, the frame symbol
+                    // after symbol
+                    float p1 = 0.0f, p2 = 0.0f, p4 = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float m2 = fma_(Y[j].im, Y[j].im, Y[j].re * Y[j].re);
+                        const bool d = carrier[j] >= 0;
+                        const float a1 = d ? __builtin_sqrtf(m2) : 0.0f, a2 = d ? m2 : 0.0f, a4 = d ? m2 * m2 : 0.0f;
+                        p1 = j ? p1 + a1 : a1; p2 = j ? p2 + a2 : a2; p4 = j ? p4 + a4 : a4;
+                    }
+                    p1 = row_xor_sum16(p1); p2 = row_xor_sum16(p2); p4 = row_xor_sum16(p4);
+                    if (act && r == 0) { stl[0] += p1; stl[1] += p2; stl[2] += p4; }
+                }
                 if (act) n_out = q + 1;
             }
         }
@@ -894,6 +916,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         fr.n_sym = (uint16_t)n_sym;
         fr.n_sym_out = (uint16_t)n_out;
         frames[out] = fr;
+        if (stat_all != nullptr) stat_all[out] = make_float4(stl[0], stl[1], stl[2], 0.0f);
     }
 }
 

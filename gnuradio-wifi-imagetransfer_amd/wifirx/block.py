@@ -23,7 +23,7 @@ import math
 
 import numpy as np
 
-from . import capi, grshim
+from . import capi, grshim, probe
 
 LS, LMS, COMB, STA = 0, 1, 2, 3
 LINKTYPE_IEEE802_11 = 105
@@ -31,7 +31,7 @@ LINKTYPE_IEEE802_11 = 105
 
 class wifi_phy_rx(grshim.sync_block):
     def __init__(self, bandwidth=10e6, chan_est=LS, encoding=0, frequency=5.89e9, sensitivity=0.56,
-                 max_sym=511, publish_carrier=True, device=0, batch_samples=1 << 20, publish_csi=False):
+                 max_sym=511, publish_carrier=True, device=0, batch_samples=1 << 20, publish_csi=False, snr_probe=None):
         grshim.sync_block.__init__(self, name="wifi_phy_rx", in_sig=[np.complex64], out_sig=None)
         self.bandwidth = float(bandwidth)
         self.chan_est = int(chan_est)
@@ -40,6 +40,13 @@ class wifi_phy_rx(grshim.sync_block):
         self.sensitivity = float(sensitivity)
         self.publish_carrier = bool(publish_carrier)
         self.publish_csi = bool(publish_csi)      # "csi" entry of the mac_out dictionary, as upstream's frame_equalizer tags it
+        # snr_probe = (type, msg_nsamples, alpha) or True for the reference's (0, 1000, 0.05): the
+        # digital.probe_mpsk_snr_est_c of gnu_radio/IRS_AP.py:275,312, fed with per-frame moments from the device
+        # (no equalised points cross the bus); its `snr` / `signal` / `noise` ports are self.snr_probe's
+        self.snr_probe = None
+        if snr_probe:
+            args = (0, 1000, 0.05) if snr_probe is True else tuple(snr_probe)
+            self.snr_probe = probe.probe_mpsk_snr_est(*args)
         self.message_port_register_out(grshim.intern("mac_out"))
         self.message_port_register_out(grshim.intern("carrier"))
         self._rx = capi.WifiRx(bandwidth=self.bandwidth, frequency=self.frequency, sensitivity=self.sensitivity,
@@ -121,12 +128,15 @@ class wifi_phy_rx(grshim.sync_block):
 
     def _publish(self):
         while True:
-            r = self._rx.poll(cap=64, psdu_stride=2048, want_csi=self.publish_csi)
+            r = self._rx.poll(cap=64, psdu_stride=2048, want_csi=self.publish_csi, want_stats=self.snr_probe is not None)
             fr = r["frames"]
             if len(fr) == 0:
                 return
             for i in range(len(fr)):
                 f = fr[i]
+                if self.snr_probe is not None and int(f["n_sym_out"]) > 0:
+                    st = r["sym_stats"][i]
+                    self.snr_probe.update_frame(st[0], st[1], st[2], 48 * int(f["n_sym_out"]))
                 if self.publish_carrier and r["carrier"] is not None:
                     for s in range(int(f["n_sym_out"])):
                         self.message_port_pub(grshim.intern("carrier"), grshim.make_pdu({}, r["carrier"][i, s]))
@@ -147,6 +157,10 @@ class wifi_phy_rx(grshim.sync_block):
                     meta["csi"] = r["csi"][i].copy()
                 blob = r["psdu"][i, :int(f["psdu_len"]) - 4].copy()
                 self.message_port_pub(grshim.intern("mac_out"), grshim.make_pdu(meta, blob))
+
+    def get_probe_snr(self):
+        """latest estimate of the SNR probe in dB (None without a probe)"""
+        return None if self.snr_probe is None else self.snr_probe.snr()
 
     def stats(self):
         return self._rx.stats()

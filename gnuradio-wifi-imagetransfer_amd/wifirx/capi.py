@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WIFIRX_LIB") or os.path.join(_HERE, "libwifirx.so")     # WIFIRX_LIB: A/B builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 EQ_LS, EQ_LMS, EQ_COMB, EQ_STA = 0, 1, 2, 3
 P_BANDWIDTH, P_FREQUENCY, P_SENSITIVITY, P_CHAN_EST, P_STREAM_BATCH, P_DECODE_SMALL_MAX, P_LLR_CSI = 1, 2, 3, 4, 5, 6, 7
 F_DETECTED, F_SYNC, F_SIGNAL, F_COMPLETE, F_LLR, F_DECODED, F_CRC_OK = 1, 2, 4, 8, 16, 32, 64
@@ -31,7 +31,7 @@ EXPORTS = [
     "wifirx_create", "wifirx_destroy", "wifirx_last_error", "wifirx_abi_version", "wifirx_set_param",
     "wifirx_get_stats", "wifirx_demod_batch", "wifirx_decode_batch", "wifirx_push", "wifirx_poll", "wifirx_poll_csi",
     "wifirx_sync", "wifirx_stream", "wifirx_synth_slots", "wifirx_dev_alloc", "wifirx_dev_free",
-    "wifirx_memcpy_h2d", "wifirx_memcpy_d2h", "wifirx_time_demod",
+    "wifirx_memcpy_h2d", "wifirx_memcpy_d2h", "wifirx_time_demod", "wifirx_poll_ex",
 ]
 
 
@@ -50,7 +50,13 @@ class Config(C.Structure):
 
 class Out(C.Structure):
     _fields_ = [("frames", C.c_void_p), ("idx", C.c_void_p), ("llr", C.c_void_p), ("carrier", C.c_void_p),
-                ("psdu", C.c_void_p), ("psdu_stride", C.c_uint32), ("on_device", C.c_uint32), ("csi", C.c_void_p)]
+                ("psdu", C.c_void_p), ("psdu_stride", C.c_uint32), ("on_device", C.c_uint32), ("csi", C.c_void_p),
+                ("sym_stats", C.c_void_p)]
+
+
+class PollOut(C.Structure):
+    _fields_ = [("frames", C.c_void_p), ("psdu", C.c_void_p), ("psdu_stride", C.c_uint32), ("reserved", C.c_uint32),
+                ("idx", C.c_void_p), ("carrier", C.c_void_p), ("csi", C.c_void_p), ("sym_stats", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -78,6 +84,7 @@ _lib.wifirx_poll.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c
                              C.c_uint32, C.POINTER(C.c_uint32)]
 _lib.wifirx_poll_csi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_uint32, C.POINTER(C.c_uint32)]
+_lib.wifirx_poll_ex.argtypes = [C.c_void_p, C.POINTER(PollOut), C.c_uint32, C.POINTER(C.c_uint32)]
 _lib.wifirx_sync.argtypes = [C.c_void_p]
 _lib.wifirx_synth_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p,
                                     C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_uint64,
@@ -180,7 +187,8 @@ class WifiRx:
         return DevBuf(self, nbytes)
 
     # -- batch mode, host buffers (PCIe-bound convenience path) --
-    def demod_batch(self, iq: np.ndarray, slot_len: int, decode=False, psdu_stride=2048, want_csi=False) -> dict:
+    def demod_batch(self, iq: np.ndarray, slot_len: int, decode=False, psdu_stride=2048, want_csi=False,
+                    want_stats=False) -> dict:
         iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
         n_slots = iq.size // slot_len
         assert n_slots * slot_len == iq.size
@@ -192,12 +200,13 @@ class WifiRx:
         psdu = np.zeros((n_slots, psdu_stride), dtype=np.uint8) if decode else None
         if not decode:
             csi = np.zeros((n_slots, 52), dtype=np.complex64) if want_csi else None
-            out = Out(_np_ptr(frames), _np_ptr(idx), _np_ptr(llr), _np_ptr(car), None, 0, 0, _np_ptr(csi))
+            stats = np.zeros((n_slots, 4), dtype=np.float32) if want_stats else None
+            out = Out(_np_ptr(frames), _np_ptr(idx), _np_ptr(llr), _np_ptr(car), None, 0, 0, _np_ptr(csi), _np_ptr(stats))
             self._check(_lib.wifirx_demod_batch(self._h, _np_ptr(iq), 0, slot_len, n_slots, C.byref(out)))
-            return dict(frames=frames, idx=idx, llr=llr, carrier=car, psdu=None, csi=csi)
+            return dict(frames=frames, idx=idx, llr=llr, carrier=car, psdu=None, csi=csi, sym_stats=stats)
         # decode needs the decisions on the device: run on device buffers, then download
         d_iq = self.alloc(iq.nbytes).upload(iq)
-        dev = self.alloc_out(n_slots, psdu_stride=psdu_stride, want_csi=want_csi)
+        dev = self.alloc_out(n_slots, psdu_stride=psdu_stride, want_csi=want_csi, want_stats=want_stats)
         try:
             self.demod_batch_dev(d_iq.ptr, slot_len, n_slots, dev)
             self.decode_batch_dev(n_slots, dev)
@@ -208,28 +217,29 @@ class WifiRx:
             self.free_out(dev)
 
     # -- batch mode, device buffers (the measured path) --
-    def alloc_out(self, n_slots, psdu_stride=0, want_csi=False) -> dict:
+    def alloc_out(self, n_slots, psdu_stride=0, want_csi=False, want_stats=False) -> dict:
         ms = self.cfg.max_sym
         d = dict(n_slots=n_slots, psdu_stride=psdu_stride)
         d["csi"] = self.alloc(n_slots * 52 * 8) if want_csi else None
+        d["sym_stats"] = self.alloc(n_slots * 16) if want_stats else None
         d["frames"] = self.alloc(n_slots * 32)
         d["idx"] = self.alloc(n_slots * ms * 48)
         d["llr"] = self.alloc(n_slots * ms * 48 * self.cfg.llr_bits * 4) if self.cfg.llr_bits else None
         d["carrier"] = self.alloc(n_slots * ms * 48 * 8) if self.cfg.want_carrier else None
         d["psdu"] = self.alloc(n_slots * psdu_stride) if psdu_stride else None
-        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi"):      # the kernels only write what a frame fills
+        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi", "sym_stats"):      # the kernels only write what a frame fills
             if d[k] is not None and d[k].nbytes:
                 d[k].upload(np.zeros(d[k].nbytes, dtype=np.uint8))
         return d
 
     def free_out(self, dev):
-        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi"):
+        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi", "sym_stats"):
             if dev.get(k) is not None:
                 dev[k].free()
 
     def _out_struct(self, dev) -> Out:
         g = lambda k: dev[k].ptr if dev.get(k) is not None else None
-        return Out(g("frames"), g("idx"), g("llr"), g("carrier"), g("psdu"), dev.get("psdu_stride", 0), 1, g("csi"))
+        return Out(g("frames"), g("idx"), g("llr"), g("carrier"), g("psdu"), dev.get("psdu_stride", 0), 1, g("csi"), g("sym_stats"))
 
     def demod_batch_dev(self, iq_ptr, slot_len, n_slots, dev):
         out = self._out_struct(dev)
@@ -249,7 +259,9 @@ class WifiRx:
         ms = self.cfg.max_sym
         r = dict(frames=dev["frames"].download(FRAME_DTYPE, n_slots),
                  idx=dev["idx"].download(np.uint8, n_slots * ms * 48).reshape(n_slots, ms, 48),
-                 llr=None, carrier=None, psdu=None, csi=None)
+                 llr=None, carrier=None, psdu=None, csi=None, sym_stats=None)
+        if dev.get("sym_stats") is not None:
+            r["sym_stats"] = dev["sym_stats"].download(np.float32, n_slots * 4).reshape(n_slots, 4)
         if dev.get("csi") is not None:
             r["csi"] = dev["csi"].download(np.complex64, n_slots * 52).reshape(n_slots, 52)
         if dev.get("llr") is not None:
@@ -272,21 +284,25 @@ class WifiRx:
         iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
         self._check(_lib.wifirx_push(self._h, _np_ptr(iq), iq.size, 0))
 
-    def poll(self, cap=256, psdu_stride=2048, want_idx=False, want_csi=False):
+    def poll(self, cap=256, psdu_stride=2048, want_idx=False, want_csi=False, want_stats=False):
         """Finished frames of the stream, oldest first (at most `cap`).  The landing buffers are kept between calls
         (a scheduler polls after every work()); what is returned are copies of the filled part."""
         ms = self.cfg.max_sym
-        key = (cap, psdu_stride, bool(want_idx), bool(want_csi))
+        key = (cap, psdu_stride, bool(want_idx), bool(want_csi), bool(want_stats))
         if getattr(self, "_poll_key", None) != key:
             self._poll_key = key
             self._poll_buf = (np.zeros(cap, dtype=FRAME_DTYPE), np.zeros((cap, psdu_stride), dtype=np.uint8),
                               np.zeros((cap, ms, 48), dtype=np.uint8) if want_idx else None,
                               np.zeros((cap, ms, 48), dtype=np.complex64) if self.cfg.want_carrier else None,
-                              np.zeros((cap, 52), dtype=np.complex64) if want_csi else None)
-        frames, psdu, idx, car, csi = self._poll_buf
+                              np.zeros((cap, 52), dtype=np.complex64) if want_csi else None,
+                              np.zeros((cap, 4), dtype=np.float32) if want_stats else None)
+            frames, psdu, idx, car, csi, stats = self._poll_buf
+            self._poll_out = PollOut(_np_ptr(frames), _np_ptr(psdu), psdu_stride, 0, _np_ptr(idx), _np_ptr(car),
+                                     _np_ptr(csi), _np_ptr(stats))
+        frames, psdu, idx, car, csi, stats = self._poll_buf
         n = C.c_uint32(0)
-        self._check(_lib.wifirx_poll_csi(self._h, _np_ptr(frames), _np_ptr(psdu), psdu_stride, _np_ptr(idx),
-                                         _np_ptr(car), _np_ptr(csi), cap, C.byref(n)))
+        self._check(_lib.wifirx_poll_ex(self._h, C.byref(self._poll_out), cap, C.byref(n)))
         n = n.value
         return dict(frames=frames[:n].copy(), psdu=psdu[:n].copy(), idx=None if idx is None else idx[:n].copy(),
-                    carrier=None if car is None else car[:n].copy(), csi=None if csi is None else csi[:n].copy())
+                    carrier=None if car is None else car[:n].copy(), csi=None if csi is None else csi[:n].copy(),
+                    sym_stats=None if stats is None else stats[:n].copy())

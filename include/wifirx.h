@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define WIFIRX_ABI_VERSION 2
+#define WIFIRX_ABI_VERSION 3
 
 /* error codes */
 #define WIFIRX_OK        0
@@ -148,7 +148,23 @@ typedef struct wifirx_out {
     uint32_t      psdu_stride;  /* bytes per slot in `psdu` (>= largest psdu_len expected) */
     uint32_t      on_device;
     float*        csi;          /* ABI 2 */
+    float*        sym_stats;    /* ABI 3: [n_slots][4] = sum |y|, sum |y|^2, sum |y|^4 over the equalised points of the
+                                   frame's n_sym_out data symbols (48 each), 0 -- the statistics a
+                                   digital.probe_mpsk_snr_est_c fed from frame_equalizer's `symbols` port accumulates
+                                   (gnu_radio/IRS_AP.py:275,312); float32 sums in the order of DESIGN.md rule 13 */
 } wifirx_out;
+
+/* Output buffers of wifirx_poll_ex (host memory; NULL = not wanted).  Row i belongs to frame i of the call. */
+typedef struct wifirx_poll_out {
+    wifirx_frame* frames;       /* [cap], required */
+    uint8_t*      psdu;         /* [cap][psdu_stride] */
+    uint32_t      psdu_stride;
+    uint32_t      reserved;
+    uint8_t*      idx;          /* [cap][max_sym][48] */
+    float*        carrier;      /* [cap][max_sym][48][2], handles created with want_carrier */
+    float*        csi;          /* [cap][52][2] */
+    float*        sym_stats;    /* [cap][4], see wifirx_out */
+} wifirx_poll_out;
 
 typedef struct wifirx_stats {
     uint64_t samples_in;     /* samples consumed */
@@ -203,6 +219,9 @@ int  wifirx_poll(wifirx_handle* h, wifirx_frame* frames, uint8_t* psdu, uint32_t
  * (read by ieee802_11.extract_csi, gnu_radio/IRS_AP.grc:640-654).  csi may be NULL. */
 int  wifirx_poll_csi(wifirx_handle* h, wifirx_frame* frames, uint8_t* psdu, uint32_t psdu_stride,
                      uint8_t* idx, float* carrier, float* csi, uint32_t cap, uint32_t* n_out);
+
+/* wifirx_poll with every per-frame output behind one struct (what later ABI versions extend). */
+int  wifirx_poll_ex(wifirx_handle* h, const wifirx_poll_out* out, uint32_t cap, uint32_t* n_out);
 
 /* block until everything queued on the handle's stream has finished */
 int  wifirx_sync(wifirx_handle* h);

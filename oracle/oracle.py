@@ -128,6 +128,16 @@ def demod_stream(x: np.ndarray, prm: Params, want_eq=False, cap=4096):
                 eq=None if eq is None else eq[:n])
 
 
+def sym_stats(eq: np.ndarray, n_sym_out: np.ndarray) -> np.ndarray:
+    """eq: [n, max_sym, 48] equalised points, n_sym_out [n] -> [n, 4] float32 (sum |y|, sum |y|^2, sum |y|^4, 0)"""
+    eq = np.ascontiguousarray(eq, dtype=np.complex64)
+    out = np.zeros((eq.shape[0], 4), dtype=np.float32)
+    for i in range(eq.shape[0]):
+        row = np.ascontiguousarray(eq[i])
+        lib().orc_sym_stats(_p(row), C.c_int(int(n_sym_out[i])), _p(out[i:i + 1]))
+    return out
+
+
 def sync_short(x: np.ndarray, threshold=0.56, min_plateau=2, math_mode=MATH_SPEC, first_only=False, cap=4096):
     x = np.ascontiguousarray(x, dtype=np.complex64).reshape(-1)
     trig = np.zeros(cap, dtype=np.int32)

@@ -1132,6 +1132,36 @@ long orc_demod_stream(const c32* x, long n_samp, const orc_params* prm, wifirx_f
     return nt;
 }
 
+/* Spec rule 13: moments of the equalised points of a frame, what a digital.probe_mpsk_snr_est_c fed from the `symbols`
+ * port accumulates (gnu_radio/IRS_AP.py:275,312).  eq: [n_sym_out][48] in carrier order.  out4 = sum |y|, sum |y|^2,
+ * sum |y|^4, 0 in float32: per symbol the 64 bins (non-data bins 0) are folded as ((a[r] + a[r+16]) + a[r+32]) + a[r+48],
+ * r = 0..15, those 16 values by the xor tree (steps 1, 2, 4, 8), and the symbols are added up in order. */
+void orc_sym_stats(const c32* eq, int n_sym_out, float* out4)
+{
+    float s[3] = { 0.0f, 0.0f, 0.0f };
+    for (int q = 0; q < n_sym_out; q++) {
+        float a[3][64];
+        memset(a, 0, sizeof a);
+        int k = 0;
+        for (int i = 6; i <= 58; i++) {
+            if (i == 11 || i == 25 || i == 32 || i == 39 || i == 53) continue;
+            const c32 y = eq[(size_t)q * 48 + k++];
+            const float m2 = fmaf(y.im, y.im, y.re * y.re);
+            a[0][i] = sqrtf(m2); a[1][i] = m2; a[2][i] = m2 * m2;
+        }
+        for (int w = 0; w < 3; w++) {
+            float p[16], t[16];
+            for (int r = 0; r < 16; r++) p[r] = ((a[w][r] + a[w][r + 16]) + a[w][r + 32]) + a[w][r + 48];
+            for (int step = 1; step < 16; step <<= 1) {
+                for (int r = 0; r < 16; r++) t[r] = p[r] + p[r ^ step];
+                memcpy(p, t, sizeof p);
+            }
+            s[w] += p[0];
+        }
+    }
+    out4[0] = s[0]; out4[1] = s[1]; out4[2] = s[2]; out4[3] = 0.0f;
+}
+
 /* small entry points for unit tests of the spec routines */
 void orc_sincos(const float* x, float* s, float* c, long n) { for (long i = 0; i < n; i++) sp_sincos(x[i], s + i, c + i); }
 void orc_atan2(const float* y, const float* x, float* r, long n) { for (long i = 0; i < n; i++) r[i] = sp_atan2(y[i], x[i]); }

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 18 and set(syms) == set(capi.EXPORTS)
     for s in syms:
         assert hasattr(capi.lib(), s), s
-    assert capi.lib().wifirx_abi_version() == capi.ABI_VERSION == 2
+    assert capi.lib().wifirx_abi_version() == capi.ABI_VERSION == 3
 
 
 def test_record_layouts():
@@ -31,12 +31,13 @@ def test_record_layouts():
     assert [capi.FRAME_DTYPE.fields[n][1] for n in capi.FRAME_DTYPE.names] == [0, 4, 8, 12, 16, 20, 24, 26, 27, 28, 30]
     # the C compiler's view of include/wifirx.h (plain C: the header must compile as C99)
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "wifirx.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(wifirx_frame), sizeof(wifirx_config), sizeof(wifirx_out), sizeof(wifirx_stats));return 0;}\n'
+    src = '#include <stdio.h>\n#include "wifirx.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(wifirx_frame), sizeof(wifirx_config), sizeof(wifirx_out), sizeof(wifirx_stats), sizeof(wifirx_poll_out));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
-    assert sizes == [32, ctypes.sizeof(capi.Config), ctypes.sizeof(capi.Out), ctypes.sizeof(capi.Stats)] == [32, 56, 56, 48]
+    assert sizes == [32, ctypes.sizeof(capi.Config), ctypes.sizeof(capi.Out), ctypes.sizeof(capi.Stats),
+                     ctypes.sizeof(capi.PollOut)] == [32, 56, 64, 48, 56]
     from oracle import oracle
     assert oracle.FRAME_DTYPE == capi.FRAME_DTYPE
 
