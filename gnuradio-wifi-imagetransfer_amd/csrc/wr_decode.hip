@@ -190,27 +190,31 @@ constexpr __host__ __device__ int rotr6(int s, int p) { return ((s >> p) | (s <<
 constexpr __host__ __device__ int parity_of(int v) { return __builtin_popcount(v) & 1; }
 
 // ---- packed 16-bit arithmetic (both halves at once; the compiler may schedule these freely) ----
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// Issue cost on gfx950 at 4-8 waves per SIMD (tools/valu_rate.hip): v_pk_* and the three-operand integer forms
+// (v_bfi_b32, v_add3_u32, ...) ~2.0 ns per wave-instruction, v_add_u32 1.5 ns, v_lshrrev_b32 1.3 ns.  Hence:
+//   * sums of two packed halves are plain 32-bit adds (no half ever reaches 2^15, so no carry crosses);
+//   * a survivor bit is the sign of (candidate 1 - candidate 0), and because all path metrics of a frame lie
+//     within 255 of each other (start penalty 64, the common minimum leaves every 120 steps) bits 8..15 of
+//     that difference all equal its sign: one v_bfi_b32 drops it into any of the bit positions 15..8 of the
+//     accumulator, eight decisions per half without a shift, then the accumulator moves down by eight.
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// acc = 2 * acc + (d < 0) per half; k15 = 0x000f000f, k2 = 0x00020002
-__device__ __forceinline__ uint32_t pk_push_sign(uint32_t acc, uint32_t d, uint32_t k15, uint32_t k2)
+// (d & mask) | (acc & ~mask)
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t d, uint32_t acc)
 {
-    uint32_t t, r;
-    asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(t) : "v"(k15), "v"(d));
-    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(k2), "v"(t));
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(d), "v"(acc));
     return r;
 }
 
+#define WR_DEC_START_PENALTY 0x00400040u      // metric of the states != 0 at step 0 (per half): only has to outlast six steps
+
 // one trellis step at register phase P: logical state s lives in pm[rotr6(s, P)] (low half: frame A, high: frame B).
 // M[a][b]: packed branch metrics of a transition whose expected coded pair is (a, b).
-// acc[k]: survivor bits of the states 16k..16k+15, first state in the top bit of each half.
+// acc[k]: survivor bits of the states 16k..16k+15, state 16k + i in bit (7 - i) & 15 of each half.
 template <int P>
-__device__ __forceinline__ void acs_step(uint32_t (&pm)[64], const uint32_t (&M)[2][2], uint32_t (&acc)[4],
-                                         uint32_t k15, uint32_t k2)
+__device__ __forceinline__ void acs_step(uint32_t (&pm)[64], const uint32_t (&M)[2][2], uint32_t (&acc)[4])
 {
-#pragma unroll
-    for (int k = 0; k < 4; k++) acc[k] = 0;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
         const int a = parity_of((j << 1) & 0155), b = parity_of((j << 1) & 0117);
@@ -218,10 +222,14 @@ __device__ __forceinline__ void acs_step(uint32_t (&pm)[64], const uint32_t (&M)
         const int r0 = rotr6(j, P), r1 = rotr6(j + 32, P);
         const uint32_t p0 = pm[r0], p1 = pm[r1];
         // state 2j (input bit 0): from j with m (candidate 0), from j+32 with mb (candidate 1);  state 2j+1: metrics swapped
-        const uint32_t c00 = pk_add(p0, m), c01 = pk_add(p1, mb), c10 = pk_add(p0, mb), c11 = pk_add(p1, m);
+        const uint32_t c00 = p0 + m, c01 = p1 + mb, c10 = p0 + mb, c11 = p1 + m;
         uint32_t& w = acc[j >> 3];
-        w = pk_push_sign(w, pk_sub(c01, c00), k15, k2);      // candidate 1 < candidate 0: survivor from j+32
-        w = pk_push_sign(w, pk_sub(c11, c10), k15, k2);
+        const int i = 2 * (j & 7);                         // decisions i, i + 1 of this word
+        if (i == 8) w >>= 8;                               // bits 15..8 are full: make room (what leaks across the halves is overwritten)
+        const uint32_t s0 = pk_sub(c01, c00), s1 = pk_sub(c11, c10);      // candidate 1 < candidate 0: survivor from j+32
+        if (i == 0) w = s0 & 0x80008000u;
+        else        w = bfi(0x80008000u >> (i & 7), s0, w);
+        w = bfi(0x80008000u >> ((i & 7) + 1), s1, w);
         pm[r0] = pk_min(c00, c01);      // = register of logical state 2j at phase P+1
         pm[r1] = pk_min(c10, c11);      // = register of logical state 2j+1 at phase P+1
     }
@@ -293,7 +301,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
     const size_t n_data_cap = n_steps_cap;               // trellis steps the scratch slice of a wave holds
     uint32_t* surv = reinterpret_cast<uint32_t*>(scratch + (size_t)wave * scratch_stride);   // [step][lane][4 pieces]
     uint32_t* dbits = surv + n_data_cap * 256;                                               // [word][A/B][lane]
-    const uint32_t k15 = 0x000f000fu, k2 = 0x00020002u, k1 = 0x00010001u;
+    const uint32_t k1 = 0x00010001u;
 
     // A wave's tasks (frames_per_wave <= 128 frames each, grid-stride); lane l owns frames base + l (l < fA) and
     // base + fA + l (l < fB).  The coded-bit masks of every task were written by decode_gather_kernel.
@@ -325,7 +333,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
         // ---- phase 2: add-compare-select ----
         uint32_t pm[64];
 #pragma unroll
-        for (int s = 0; s < 64; s++) pm[s] = (s == 0) ? 0u : 0x10001000u;
+        for (int s = 0; s < 64; s++) pm[s] = (s == 0) ? 0u : WR_DEC_START_PENALTY;
         int best[2] = { 0, 0 };                         // final states, taken when the frames end
         for (int t0 = 0, c = 0; t0 < n_max; t0 += WR_DEC_CHUNK, c++) {
             // my two frames' mask words of this chunk: global -> LDS (lane-private slots), re-read six steps at a time
@@ -371,7 +379,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                             M[1][1] = nv - M[0][0];                                                       \
                             M[1][0] = nv - M[0][1];                                                       \
                             uint32_t acc[4];                                                              \
-                            acs_step<P>(pm, M, acc, k15, k2);                                             \
+                            acs_step<P>(pm, M, acc);                                             \
                             *reinterpret_cast<uint4*>(surv + ((size_t)(tg + P) * 64 + lane) * 4) =        \
                                 make_uint4(acc[0], acc[1], acc[2], acc[3]);                               \
                         }
@@ -418,7 +426,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                     const int i0 = st0 >> 4, i1 = st1 >> 4;
                     const uint32_t p0 = i0 == 0 ? rows[k].x : i0 == 1 ? rows[k].y : i0 == 2 ? rows[k].z : rows[k].w;
                     const uint32_t p1 = i1 == 0 ? rows[k].x : i1 == 1 ? rows[k].y : i1 == 2 ? rows[k].z : rows[k].w;
-                    const uint32_t h0 = (p0 >> (15 - (st0 & 15))) & 1u, h1 = (p1 >> (31 - (st1 & 15))) & 1u;
+                    const uint32_t h0 = (p0 >> ((7 - st0) & 15)) & 1u, h1 = (p1 >> (16 + ((7 - st1) & 15))) & 1u;
                     if (mine0) {
                         word0 |= (uint32_t)(st0 & 1) << (t & 31);
                         st0 = (st0 >> 1) | (int)(h0 << 5);

@@ -29,6 +29,28 @@ __global__ __launch_bounds__(256) void k(float* out, int iters)
             asm volatile("v_cmp_lt_i32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n v_cmp_lt_i32 vcc, %1, %3\n v_cndmask_b32 %1, %1, %3, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "vcc");
         } else if (KIND == 9) {
             asm volatile("v_pk_sub_i16 %0, %0, %4\n v_pk_lshrrev_b16 %1, 15, %1\n v_pk_mad_u16 %2, %2, %4, %1\n v_pk_sub_i16 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        } else if (KIND == 10) {
+            asm volatile("v_add3_u32 %0, %0, %4, %4\n v_add3_u32 %1, %1, %4, %4\n v_add3_u32 %2, %2, %4, %4\n v_add3_u32 %3, %3, %4, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        } else if (KIND == 11) {
+            asm volatile("v_lshl_add_u32 %0, %0, 1, %4\n v_lshl_add_u32 %1, %1, 1, %4\n v_lshl_add_u32 %2, %2, 1, %4\n v_lshl_add_u32 %3, %3, 1, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        } else if (KIND == 12) {
+            asm volatile("v_and_or_b32 %0, %0, %4, %4\n v_and_or_b32 %1, %1, %4, %4\n v_and_or_b32 %2, %2, %4, %4\n v_and_or_b32 %3, %3, %4, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        } else if (KIND == 13) {
+            asm volatile("v_min_u32 %0, %0, %4\n v_min_u32 %1, %1, %4\n v_min_u32 %2, %2, %4\n v_min_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        } else if (KIND == 14) {
+            asm volatile("v_cmp_lt_u16 vcc, %0, %1\n v_cmp_lt_u16 vcc, %1, %2\n v_cmp_lt_u16 vcc, %2, %3\n v_cmp_lt_u16 vcc, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) :: "vcc");
+        } else if (KIND == 15) {
+            asm volatile("v_pk_sub_i16 %0, %0, %4\n v_pk_sub_i16 %1, %1, %4\n v_pk_sub_i16 %2, %2, %4\n v_pk_sub_i16 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        } else if (KIND == 16) {
+            asm volatile("v_pk_lshrrev_b16 %0, 15, %0\n v_pk_lshrrev_b16 %1, 15, %1\n v_pk_lshrrev_b16 %2, 15, %2\n v_pk_lshrrev_b16 %3, 15, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        } else if (KIND == 17) {
+            asm volatile("v_pk_mad_u16 %0, %0, %4, %1\n v_pk_mad_u16 %1, %1, %4, %2\n v_pk_mad_u16 %2, %2, %4, %3\n v_pk_mad_u16 %3, %3, %4, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        } else if (KIND == 18) {
+            asm volatile("v_sub_u32 %0, %0, %4\n v_sub_u32 %1, %1, %4\n v_sub_u32 %2, %2, %4\n v_sub_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        } else if (KIND == 19) {
+            asm volatile("v_bfi_b32 %0, %4, %0, %1\n v_bfi_b32 %1, %4, %1, %2\n v_bfi_b32 %2, %4, %2, %3\n v_bfi_b32 %3, %4, %3, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+        } else if (KIND == 20) {
+            asm volatile("v_lshrrev_b32 %0, 1, %0\n v_lshrrev_b32 %1, 1, %1\n v_lshrrev_b32 %2, 1, %2\n v_lshrrev_b32 %3, 1, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
         } else {
             asm volatile("v_pk_fma_f16 %0, %0, %4, %4\n v_pk_fma_f16 %1, %1, %4, %4\n v_pk_fma_f16 %2, %2, %4, %4\n v_pk_fma_f16 %3, %3, %4, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
         }
@@ -51,6 +73,9 @@ int main()
 {
     for (int w : {1, 2, 4, 8}) { run<0>("v_fma_f32", 8, w); }
     for (int w : {1, 4}) { run<1>("v_pk_fma_f32", 4, w); run<2>("v_fma_f64", 4, w); run<3>("v_rcp_f32", 4, w); }
-    for (int w : {4, 8}) { run<4>("v_pk_add_u16", 4, w); run<5>("v_pk_min_u16", 4, w); run<6>("v_add_u32", 4, w); run<7>("cmp+cndmask+addc", 6, w); run<8>("v_pk_fma_f16", 4, w); run<9>("pk sub/lshr/mad", 4, w); }
+    for (int w : {4, 8}) { run<4>("v_pk_add_u16", 4, w); run<5>("v_pk_min_u16", 4, w); run<6>("v_add_u32", 4, w); run<7>("cmp+cndmask+addc", 6, w); run<8>("v_pk_fma_f16", 4, w); run<9>("pk sub/lshr/mad", 4, w);
+        run<10>("v_add3_u32", 4, w); run<11>("v_lshl_add_u32", 4, w); run<12>("v_and_or_b32", 4, w); run<13>("v_min_u32", 4, w);
+        run<14>("v_cmp_lt_u16", 4, w); run<15>("v_pk_sub_i16", 4, w); run<16>("v_pk_lshrrev_b16", 4, w); run<17>("v_pk_mad_u16", 4, w);
+        run<18>("v_sub_u32", 4, w); run<19>("v_bfi_b32", 4, w); run<20>("v_lshrrev_b32", 4, w); }
     return 0;
 }
