@@ -11,6 +11,9 @@
 #ifndef WR_DEMOD_WAVES_PER_SIMD
 #define WR_DEMOD_WAVES_PER_SIMD 4       // register budget of the demod kernels: 512/4 = 128 VGPRs
 #endif
+#ifndef WR_DEMOD_WAVES_PER_SIMD_STA
+#define WR_DEMOD_WAVES_PER_SIMD_STA 3   // STA alone runs faster with 168 registers (25.9 vs 28.8 ms on config 2: 19 spills at 128)
+#endif
 #define WR_STREAM_SPAN     16       // tiles of 64 samples one wave scans in stream-mode detection
 #define WR_DECODE_MAX_WAVES 4096    // waves of the decode kernel (grid-stride; each owns a scratch slice)
 #define WR_DECODE_SMALL_MAX 16384      // batches up to this many frames take the wave-per-frame decode kernel

@@ -154,7 +154,7 @@ __device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n
 // Preamble phase per slot with the whole wave (lane = sample / lag), then the four frames walk their
 // symbols together (wr_quad.h).
 template <int EQ>
-__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ != WIFIRX_EQ_LS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
+__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ == WIFIRX_EQ_STA ? WR_DEMOD_WAVES_PER_SIMD_STA : WR_DEMOD_WAVES_PER_SIMD)
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
                         DemodParams prm, DemodOut out)
 {
@@ -235,7 +235,7 @@ void stream_detect_kernel(const float2* __restrict__ x, long n_samp, long tile0,
 
 // one wave per four selected triggers of the stream
 template <int EQ>
-__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ != WIFIRX_EQ_LS ? 3 : WR_DEMOD_WAVES_PER_SIMD)
+__global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ == WIFIRX_EQ_STA ? WR_DEMOD_WAVES_PER_SIMD_STA : WR_DEMOD_WAVES_PER_SIMD)
 void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const StreamTrig* __restrict__ trig,
                          uint32_t n_trig, DemodParams prm, const float2* __restrict__ A, DemodOut out)
 {

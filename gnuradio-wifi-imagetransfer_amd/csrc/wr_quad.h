@@ -765,15 +765,16 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 if (!DIV || carrier[j] >= 0) {
                     const float2 g0 = DHl[64 * j];
                     if (DIV) {
-                        const float d = fma_(g0.y, g0.y, g0.x * g0.x);
-                        Y[j].re = fma_(X[j].im, g0.y, X[j].re * g0.x) / d;
-                        Y[j].im = fma_(X[j].im, g0.x, -(X[j].re * g0.y)) / d;
+                        // spec rule 11: one reciprocal of |H|^2 per bin, then products
+                        const float rd = 1.0f / fma_(g0.y, g0.y, g0.x * g0.x);
+                        Y[j].re = fma_(X[j].im, g0.y, X[j].re * g0.x) * rd;
+                        Y[j].im = fma_(X[j].im, g0.x, -(X[j].re * g0.y)) * rd;
                         if (LMS || STA) {
                             const int nbl = (s == 2) ? 1 : n_bpsc;
                             const c32 pt = point_of(decide(Y[j], nbl), nbl);
-                            const float dp = fma_(pt.im, pt.im, pt.re * pt.re);
-                            const float tr = fma_(X[j].im, pt.im, X[j].re * pt.re) / dp;
-                            const float ti = fma_(X[j].im, pt.re, -(X[j].re * pt.im)) / dp;
+                            const float rp = 1.0f / fma_(pt.im, pt.im, pt.re * pt.re);
+                            const float tr = fma_(X[j].im, pt.im, X[j].re * pt.re) * rp;
+                            const float ti = fma_(X[j].im, pt.re, -(X[j].re * pt.im)) * rp;
                             if (LMS && act) Hl[64 * j] = make_float2(0.5f * g0.x + 0.5f * tr, 0.5f * g0.y + 0.5f * ti);
                             HU[j] = { tr, ti };
                         }
@@ -808,9 +809,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                         const c32 add = (cnt > 0) ? cadd(sum, c32{ v.x, v.y }) : c32{ v.x, v.y };
                         if (ok) { sum = add; cnt++; }
                     }
-                    const float fc_ = (float)(cnt > 0 ? cnt : 1);
+                    const float inv = cnt == 3 ? 0x1.555556p-2f : cnt == 4 ? 0.25f : 0x1.99999ap-3f;     // 1/3, 1/4, 1/5 in float32
                     const float2 o = Hl[64 * j];
-                    if (act && usedj) Hl[64 * j] = make_float2(0.5f * o.x + 0.5f * (sum.re / fc_), 0.5f * o.y + 0.5f * (sum.im / fc_));
+                    if (act && usedj) Hl[64 * j] = make_float2(0.5f * o.x + 0.5f * (sum.re * inv), 0.5f * o.y + 0.5f * (sum.im * inv));
                 }
                 __builtin_amdgcn_wave_barrier();
             }

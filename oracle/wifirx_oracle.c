@@ -890,6 +890,11 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 for (int i = 6; i <= 58; i++) if (i != 32) csi[k++] = H[i];
             }
         } else {
+            /* spec rule 11: X / H as conj(H) X times ONE reciprocal, r = 1 / |H|^2 (a correctly rounded division), then two
+             * products -- not two divisions */
+#define SP_CDIV(X_, H_, OUT_) do { const float d_ = fmaf((H_).im, (H_).im, (H_).re * (H_).re); const float r_ = 1.0f / d_;         \
+                                   (OUT_).re = fmaf((X_).im, (H_).im, (X_).re * (H_).re) * r_;                                      \
+                                   (OUT_).im = fmaf((X_).im, (H_).re, -((X_).re * (H_).im)) * r_; } while (0)
             uint8_t bits48[48];
             int     bin48[48];
             c32     sym48[48];
@@ -902,26 +907,18 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 c32 yq;
                 if (prm->chan_est == WIFIRX_EQ_COMB || prm->chan_est == WIFIRX_EQ_STA) {
                     /* Y = X / d_H (for STA: the estimate of the previous symbol; it is updated below) */
-                    float d = fmaf(DH[i].im, DH[i].im, DH[i].re * DH[i].re);
-                    yq.re = fmaf(X[i].im, DH[i].im, X[i].re * DH[i].re) / d;
-                    yq.im = fmaf(X[i].im, DH[i].re, -(X[i].re * DH[i].im)) / d;
+                    SP_CDIV(X[i], DH[i], yq);
                     if (prm->chan_est == WIFIRX_EQ_STA) {
                         c32 pt = point_of(decide(yq, nb), nb);
-                        float dp = fmaf(pt.im, pt.im, pt.re * pt.re);
-                        HU[i].re = fmaf(X[i].im, pt.im, X[i].re * pt.re) / dp;
-                        HU[i].im = fmaf(X[i].im, pt.re, -(X[i].re * pt.im)) / dp;
+                        SP_CDIV(X[i], pt, HU[i]);
                     }
                 } else if (spec && prm->chan_est == WIFIRX_EQ_LMS) {
                     /* LMS (decision directed): Y = X/H, then H = H/2 + (X/point)/2 */
-                    float d = fmaf(H[i].im, H[i].im, H[i].re * H[i].re);
-                    yq.re = fmaf(X[i].im, H[i].im, X[i].re * H[i].re) / d;
-                    yq.im = fmaf(X[i].im, H[i].re, -(X[i].re * H[i].im)) / d;
-                    c32 pt = point_of(decide(yq, nb), nb);
-                    float dp = fmaf(pt.im, pt.im, pt.re * pt.re);
-                    float tr = fmaf(X[i].im, pt.im, X[i].re * pt.re) / dp;
-                    float ti = fmaf(X[i].im, pt.re, -(X[i].re * pt.im)) / dp;
-                    H[i].re = 0.5f * H[i].re + 0.5f * tr;
-                    H[i].im = 0.5f * H[i].im + 0.5f * ti;
+                    SP_CDIV(X[i], H[i], yq);
+                    c32 pt = point_of(decide(yq, nb), nb), tq;
+                    SP_CDIV(X[i], pt, tq);
+                    H[i].re = 0.5f * H[i].re + 0.5f * tq.re;
+                    H[i].im = 0.5f * H[i].im + 0.5f * tq.im;
                 } else if (spec) {
                     yq = sp_cmul(X[i], G[i]);
                 } else if (prm->chan_est == WIFIRX_EQ_LMS) {
@@ -959,8 +956,10 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                         sum = cnt ? cadd(sum, HU[k]) : HU[k];
                         cnt++;
                     }
-                    NH[i].re = 0.5f * DH[i].re + 0.5f * (sum.re / (float)cnt);
-                    NH[i].im = 0.5f * DH[i].im + 0.5f * (sum.im / (float)cnt);
+                    /* the mean over 3, 4 or 5 bins: times the float32 reciprocal of the count */
+                    const float inv = cnt == 3 ? 0x1.555556p-2f : cnt == 4 ? 0.25f : 0x1.99999ap-3f;
+                    NH[i].re = 0.5f * DH[i].re + 0.5f * (sum.re * inv);
+                    NH[i].im = 0.5f * DH[i].im + 0.5f * (sum.im * inv);
                 }
                 for (int i = 6; i <= 58; i++) if (i != 32) DH[i] = NH[i];
             }

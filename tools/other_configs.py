@@ -27,7 +27,7 @@ CASES = [   # name, encoding, PSDU bytes, slot length
 def main():
     n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
     res = []
-    for name, enc, plen, slot_len in CASES:
+    for name, enc, plen, slot_len in (CASES if not os.environ.get("WIFIRX_ONLY_EQ") else []):
         n_sym = txgen.n_sym_for(plen, enc)
         n_bpsc = txgen.RATE_TABLE[enc][0]
         tx = txgen.encode_psdus(txgen.make_psdus(256, plen, seed=5), enc)
@@ -51,19 +51,24 @@ def main():
         rx.free_out(dev); slots.free(); rx.close()
     # the other equalisers on config 2's geometry (their kernel instances are parity-tested, not tuned)
     eqs = []
-    name, enc, plen, slot_len = CASES[-1]
-    n_sym, n_bpsc = txgen.n_sym_for(plen, enc), txgen.RATE_TABLE[enc][0]
-    tx = txgen.encode_psdus(txgen.make_psdus(256, plen, seed=5), enc)
-    for ce, en in enumerate(("LS", "LMS", "COMB", "STA")):
+    for name, enc, plen, slot_len in (CASES[-1], CASES[0]):
+      n_sym, n_bpsc = txgen.n_sym_for(plen, enc), txgen.RATE_TABLE[enc][0]
+      tx = txgen.encode_psdus(txgen.make_psdus(256, plen, seed=5), enc)
+      for ce, en in enumerate(("LS", "LMS", "COMB", "STA")):
         rx = capi.WifiRx(max_sym=n_sym, llr_bits=n_bpsc, chan_est=ce)
         slots = rx.alloc(n_frames * slot_len * 8)
         dev = rx.alloc_out(n_frames, psdu_stride=320)
         rx.synth_slots(tx.samples, slots.ptr, slot_len, n_frames, 160, 25.0, 0.037, 77)
         rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=1)
         ms = rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=5)
-        eqs.append({"chan_est": en, "demod_ms": ms, "gsamples_per_s": n_frames * slot_len / ms / 1e6})
+        eqs.append({"geometry": name, "chan_est": en, "demod_ms": ms, "gsamples_per_s": n_frames * slot_len / ms / 1e6})
         rx.free_out(dev); slots.free(); rx.close()
-    print(json.dumps({"cases": res, "equalisers_on_config_2": eqs}))
+    for e in eqs:
+        ls = [x for x in eqs if x["geometry"] == e["geometry"] and x["chan_est"] == "LS"][0]
+        e["vs_LS"] = e["demod_ms"] / ls["demod_ms"]
+    if os.environ.get("WIFIRX_ONLY_EQ"):
+        res = []
+    print(json.dumps({"cases": res, "equalisers": eqs}))
 
 
 if __name__ == "__main__":
