@@ -9,21 +9,24 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
 #include "wifirx.h"
 #include "wr_kernels.h"
 
+// A finished frame of the stream: its record and where its outputs sit in the (shared) host copy of its batch.
 struct PolledFrame {
-    wifirx_frame          fr;
-    std::vector<uint8_t>  psdu;
-    std::vector<uint8_t>  idx;
-    std::vector<float>    carrier;
-    float                 csi[104];
-    float                 stats[4];
+    wifirx_frame                           fr;
+    std::shared_ptr<std::vector<uint8_t>>  blob;
+    size_t   o_psdu = 0, o_idx = 0, o_car = 0, o_csi = 0, o_stats = 0;     // byte offsets into *blob
+    uint32_t n_psdu = 0, n_idx = 0, n_car = 0;                              // bytes, bytes, floats
 };
 
 struct PendingTrig {
@@ -65,6 +68,7 @@ struct wifirx_handle {
     int64_t  stream_batch = 0;      // WIFIRX_P_STREAM_BATCH
     uint32_t decode_small_max = WR_DECODE_SMALL_MAX;   // WIFIRX_P_DECODE_SMALL_MAX
     int32_t  llr_csi = 0;           // WIFIRX_P_LLR_CSI
+    int32_t  stream_want_idx = 1;   // WIFIRX_P_STREAM_IDX
     int64_t  sprocessed = 0;        // absolute index up to which pushes have been processed
     uint8_t* s_above = nullptr;     float2* s_A = nullptr;    int64_t s_above_cap = 0;
     std::vector<PendingTrig> pending;
@@ -74,6 +78,17 @@ struct wifirx_handle {
     void*  s_csi = nullptr;
     void*  s_stats = nullptr;
     int    test_fail_alloc = 0, test_alloc_count = 0;      // WIFIRX_TEST_FAIL_ALLOC (allocation-failure tests)
+
+    // Host-buffer stream path (what a GNU Radio work() drives; wifirx_api_stream.inc): pushes are copied into one of two
+    // pinned staging buffers of one batch each; a full one is handed to the worker thread, which runs the device
+    // pipeline for it while the caller fills the other.  `mu` guards the job slot, the frame queue and the statistics.
+    std::mutex              mu;
+    std::condition_variable cv;
+    std::thread             worker;
+    bool    w_started = false, w_stop = false, w_busy = false, w_has_job = false;
+    const float* w_job_ptr = nullptr;   size_t w_job_n = 0;   bool w_job_flush = false;
+    int     w_rc = 0;                   std::string w_err;     // first failure of a batch, reported by the next call
+    float2* ring[2] = { nullptr, nullptr };   size_t ring_cap = 0, ring_fill = 0;   int ring_cur = 0;
 };
 
 namespace {
@@ -131,6 +146,9 @@ wr::DemodParams params_of(const wifirx_handle* h)
 
 }  // namespace
 
+static void stream_worker_stop(wifirx_handle* h);
+static void stream_worker_wait_idle(wifirx_handle* h);
+
 extern "C" {
 
 int wifirx_abi_version(void) { return WIFIRX_ABI_VERSION; }
@@ -174,8 +192,10 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
 int wifirx_destroy(wifirx_handle* h)
 {
     if (!h) return WIFIRX_EINVAL;
+    stream_worker_stop(h);
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (float2* r : h->ring) if (r) (void)hipHostFree(r);
     void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi, h->stage_stats, h->s_stats,
                      h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx,
                      h->s_car, h->s_psdu, h->s_csi };
@@ -192,6 +212,7 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
 {
     if (!h) return WIFIRX_EINVAL;
     if (!std::isfinite(value)) return fail(h, WIFIRX_EINVAL, "parameter value must be finite");
+    stream_worker_wait_idle(h);            // a batch in flight keeps the parameters it started with
     switch (id) {
     case WIFIRX_P_BANDWIDTH:
         if (!(value > 0)) return fail(h, WIFIRX_EINVAL, "bandwidth must be > 0");
@@ -212,6 +233,9 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
     case WIFIRX_P_LLR_CSI:
         h->llr_csi = value != 0;
         return WIFIRX_OK;
+    case WIFIRX_P_STREAM_IDX:
+        h->stream_want_idx = value != 0;
+        return WIFIRX_OK;
     case WIFIRX_P_DECODE_SMALL_MAX:
         if (!(value >= 0) || value > 4e9) return fail(h, WIFIRX_EINVAL, "decode threshold out of range");
         h->decode_small_max = (uint32_t)value;
@@ -228,6 +252,7 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
 int wifirx_get_stats(const wifirx_handle* h, wifirx_stats* st)
 {
     if (!h || !st) return WIFIRX_EINVAL;
+    std::lock_guard<std::mutex> lk(const_cast<wifirx_handle*>(h)->mu);
     *st = h->stats;
     return WIFIRX_OK;
 }
@@ -237,6 +262,7 @@ void* wifirx_stream(wifirx_handle* h) { return h ? (void*)h->stream : nullptr; }
 int wifirx_sync(wifirx_handle* h)
 {
     if (!h) return WIFIRX_EINVAL;
+    stream_worker_wait_idle(h);
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return WIFIRX_OK;

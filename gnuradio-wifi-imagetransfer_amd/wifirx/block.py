@@ -19,6 +19,7 @@ never raises for channel conditions.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 
 import numpy as np
@@ -26,12 +27,14 @@ import numpy as np
 from . import capi, grshim, probe
 
 LS, LMS, COMB, STA = 0, 1, 2, 3
+_C64 = np.dtype(np.complex64)
+_ANCHOR = ctypes.c_char * 1
 LINKTYPE_IEEE802_11 = 105
 
 
 class wifi_phy_rx(grshim.sync_block):
     def __init__(self, bandwidth=10e6, chan_est=LS, encoding=0, frequency=5.89e9, sensitivity=0.56,
-                 max_sym=511, publish_carrier=True, device=0, batch_samples=1 << 20, publish_csi=False, snr_probe=None):
+                 max_sym=511, publish_carrier=True, device=0, batch_samples=1 << 22, publish_csi=False, snr_probe=None):
         grshim.sync_block.__init__(self, name="wifi_phy_rx", in_sig=[np.complex64], out_sig=None)
         self.bandwidth = float(bandwidth)
         self.chan_est = int(chan_est)
@@ -52,11 +55,18 @@ class wifi_phy_rx(grshim.sync_block):
         self._rx = capi.WifiRx(bandwidth=self.bandwidth, frequency=self.frequency, sensitivity=self.sensitivity,
                                chan_est=self.chan_est, max_sym=max_sym, llr_bits=0,
                                want_carrier=self.publish_carrier, device=device)
-        # The scheduler calls work() with a few thousand items; the GPU pipeline runs once `batch_samples` have come in
-        # (about 50 ms of signal at 20 MS/s) -- one device round trip per work() call could not keep up -- and at stop().
+        # The scheduler calls work() with a few thousand items.  The library copies them into a pinned staging buffer
+        # and returns; once `batch_samples` have come in (about 0.2 s of signal at 20 MS/s) its worker thread runs the
+        # device pipeline for that batch while work() keeps filling the next one -- one device round trip per work()
+        # call could not keep up.  Finished frames are fetched once per batch, and at stop().
         self.batch_samples = int(batch_samples)
         self._rx.set_param(capi.P_STREAM_BATCH, self.batch_samples)
-        self._pend, self._pend_n = [], 0
+        self._rx.set_param(capi.P_STREAM_IDX, 0)            # PDUs only: the hard decisions stay on the device
+        self._push = capi.lib().wifirx_push
+        self._h = self._rx._h
+        self._since_poll = 0
+        self._p_mac = grshim.intern("mac_out")
+        self._p_car = grshim.intern("carrier")
         self.frames_ok = 0
         self.frames_dropped = 0
 
@@ -102,61 +112,72 @@ class wifi_phy_rx(grshim.sync_block):
     def work(self, input_items, output_items):
         x = input_items[0]
         n = len(x)
-        if n >= self.batch_samples and not self._pend:
-            self._rx.push(x)                              # a chunk that is a batch by itself goes straight through
-            self._publish()
-        elif n:
-            # the scheduler owns the input buffer: keep a copy and hand the library one piece per batch
-            self._pend.append(np.array(x, dtype=np.complex64, copy=True))
-            self._pend_n += n
-            if self._pend_n >= self.batch_samples:
-                self._flush_pending()
+        if n:
+            if x.dtype != _C64 or not x.flags.c_contiguous:
+                x = np.ascontiguousarray(x, dtype=np.complex64)
+            try:
+                buf = _ANCHOR.from_buffer(x)                 # the address of x's data, without building a dict
+            except (TypeError, ValueError):                  # read-only input: the slower route
+                buf = x.ctypes.data
+            rc = self._push(self._h, buf, n, 0)              # copies; x is the scheduler's again
+            if rc:
+                self._rx._check(rc)
+            self._since_poll += n
+            if self._since_poll >= self.batch_samples:
+                self._since_poll = 0
                 self._publish()
         return n
 
-    def _flush_pending(self):
-        if self._pend:
-            self._rx.push(self._pend[0] if len(self._pend) == 1 else np.concatenate(self._pend))
-            self._pend, self._pend_n = [], 0
-
     def stop(self):
         """End of stream: settle the frames still waiting for samples."""
-        self._flush_pending()
-        self._rx.push(np.zeros(0, dtype=np.complex64))
+        self._rx._check(self._push(self._h, None, 0, 0))
+        self._since_poll = 0
         self._publish()
         return True
 
     def _publish(self):
+        """Everything the library has finished so far, as PDUs.  Per-frame fields are taken out of the record array
+        column by column (one tolist() per field, not a NumPy scalar conversion per frame and field)."""
+        pub, make = self.message_port_pub, grshim.make_pdu
+        want_car = self.publish_carrier
         while True:
-            r = self._rx.poll(cap=64, psdu_stride=2048, want_csi=self.publish_csi, want_stats=self.snr_probe is not None)
+            r = self._rx.poll(cap=1024, psdu_stride=2048, want_csi=self.publish_csi, want_stats=self.snr_probe is not None)
             fr = r["frames"]
-            if len(fr) == 0:
+            nf = len(fr)
+            if nf == 0:
                 return
-            for i in range(len(fr)):
-                f = fr[i]
-                if self.snr_probe is not None and int(f["n_sym_out"]) > 0:
-                    st = r["sym_stats"][i]
-                    self.snr_probe.update_frame(st[0], st[1], st[2], 48 * int(f["n_sym_out"]))
-                if self.publish_carrier and r["carrier"] is not None:
-                    for s in range(int(f["n_sym_out"])):
-                        self.message_port_pub(grshim.intern("carrier"), grshim.make_pdu({}, r["carrier"][i, s]))
-                if not (int(f["flags"]) & capi.F_CRC_OK):
-                    self.frames_dropped += 1
-                    continue
-                self.frames_ok += 1
-                tag = float(np.float64(f["cfo_coarse"]) - np.float64(f["cfo_fine"]))
-                meta = {
-                    "frame_bytes": int(f["psdu_len"]),
-                    "encoding": int(f["encoding"]),
-                    "snr": float(f["snr_db"]),
-                    "freq": self.frequency,
-                    "freq_offset": tag * self.bandwidth / (2 * math.pi),
-                    "dlt": LINKTYPE_IEEE802_11,
-                }
-                if self.publish_csi:
-                    meta["csi"] = r["csi"][i].copy()
-                blob = r["psdu"][i, :int(f["psdu_len"]) - 4].copy()
-                self.message_port_pub(grshim.intern("mac_out"), grshim.make_pdu(meta, blob))
+            flags = fr["flags"].tolist()
+            n_out = fr["n_sym_out"].tolist()
+            if self.snr_probe is not None:
+                st = r["sym_stats"].tolist()
+                for i in range(nf):
+                    if n_out[i] > 0:
+                        self.snr_probe.update_frame(st[i][0], st[i][1], st[i][2], 48 * n_out[i])
+            if want_car and r["carrier"] is not None:
+                car = r["carrier"]
+                for i in range(nf):
+                    for sy in range(n_out[i]):
+                        pub(self._p_car, make({}, car[i, sy]))
+            ok = [i for i in range(nf) if flags[i] & capi.F_CRC_OK]
+            self.frames_ok += len(ok)
+            self.frames_dropped += nf - len(ok)
+            if not ok:
+                continue
+            plen = fr["psdu_len"].tolist()
+            enc = fr["encoding"].tolist()
+            snr = fr["snr_db"].tolist()
+            # sync_long's wifi_start tag as upstream forms it: (double)cfo_coarse - (double)cfo_fine
+            foff = ((fr["cfo_coarse"].astype(np.float64) - fr["cfo_fine"].astype(np.float64))
+                    * (self.bandwidth / (2 * math.pi))).tolist()
+            psdu = r["psdu"]
+            freq = self.frequency
+            csi = r["csi"] if self.publish_csi else None
+            for i in ok:
+                meta = {"frame_bytes": plen[i], "encoding": enc[i], "snr": snr[i], "freq": freq,
+                        "freq_offset": foff[i], "dlt": LINKTYPE_IEEE802_11}
+                if csi is not None:
+                    meta["csi"] = csi[i].copy()
+                pub(self._p_mac, make(meta, psdu[i, :plen[i] - 4].copy()))
 
     def get_probe_snr(self):
         """latest estimate of the SNR probe in dB (None without a probe)"""

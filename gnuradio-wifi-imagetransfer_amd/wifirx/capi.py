@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WIFIRX_LIB") or os.path.join(_HERE, "libwifirx.so")  
 
 ABI_VERSION = 3
 EQ_LS, EQ_LMS, EQ_COMB, EQ_STA = 0, 1, 2, 3
-P_BANDWIDTH, P_FREQUENCY, P_SENSITIVITY, P_CHAN_EST, P_STREAM_BATCH, P_DECODE_SMALL_MAX, P_LLR_CSI = 1, 2, 3, 4, 5, 6, 7
+P_BANDWIDTH, P_FREQUENCY, P_SENSITIVITY, P_CHAN_EST, P_STREAM_BATCH, P_DECODE_SMALL_MAX, P_LLR_CSI, P_STREAM_IDX = 1, 2, 3, 4, 5, 6, 7, 8
 F_DETECTED, F_SYNC, F_SIGNAL, F_COMPLETE, F_LLR, F_DECODED, F_CRC_OK = 1, 2, 4, 8, 16, 32, 64
 
 FRAME_DTYPE = np.dtype([

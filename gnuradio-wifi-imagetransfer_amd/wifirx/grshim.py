@@ -31,7 +31,7 @@ def make_pdu(meta: dict, vec: np.ndarray):
     if HAVE_GNURADIO:  # pragma: no cover
         d = _pmt.to_pmt(dict(meta))
         return _pmt.cons(d, _pmt.to_pmt(np.ascontiguousarray(vec)))
-    return (dict(meta), np.ascontiguousarray(vec))
+    return (meta, vec if vec.flags.c_contiguous else np.ascontiguousarray(vec))
 
 
 def to_python(msg):

@@ -121,6 +121,9 @@ typedef struct wifirx_config {
 /* 1: every LLR is multiplied by |H|^2 of its sub-carrier (the LS channel estimate of the two long training
  * symbols; the optional channel-state weight of SURVEY.md section 8 row a7).  Default 0: plain max-log LLRs. */
 #define WIFIRX_P_LLR_CSI 7
+/* stream mode: 0 = the hard decisions of the frames stay on the device (wifirx_poll* then delivers zeros for `idx`);
+ * default 1.  A consumer of PDUs only (the wifi_phy_rx block) saves most of the device-to-host traffic of a push. */
+#define WIFIRX_P_STREAM_IDX 8
 
 typedef struct wifirx_handle wifirx_handle;
 
@@ -190,7 +193,10 @@ int  wifirx_get_stats(const wifirx_handle* h, wifirx_stats* st);
  * sample stream that starts in sync_short's SEARCH state; the first frame of every slot is
  * demodulated:  autocorrelation graph + sync_short + sync_long + fft_vcc + frame_equalizer
  * (gnu_radio/IRS_AP.py:268-269,271,273,276-285).  Asynchronous on the handle's stream when all
- * buffers are on the device; call wifirx_sync() before reading results. */
+ * buffers are on the device; call wifirx_sync() before reading results.
+ * Slots have ONE common length: there is no slot_off[] table of per-slot offsets (SURVEY.md 8(b) sketched one).
+ * Recordings of unequal length are padded to the longest (trailing samples of a slot cost nothing: the kernel stops
+ * reading a slot after its frame's last symbol) or go through stream mode (wifirx_push), which has no slot notion. */
 int  wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device,
                         uint32_t slot_len, uint32_t n_slots, const wifirx_out* out);
 
