@@ -241,43 +241,76 @@ __device__ __forceinline__ uint32_t crc32_bit(uint32_t c, uint32_t bit)
     return (c >> 1) ^ (0xedb88320u & (0u - x));
 }
 
-// descramble (x^7+x^4+1, state from the first 7 decoded bits), bytes, CRC-32 of one frame; db = its decoded words
-// (stride 128 dwords, two spare words behind the last one).  The next word is fetched while the current one is
-// consumed; PSDU bytes leave four at a time when the row is dword-aligned (wave-uniform `dword_ok`).
-__device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, int psdu_len, uint8_t* __restrict__ psdu,
-                                             bool dword_ok, wifirx_frame* __restrict__ rec, uint32_t flags)
+// Tables of the per-frame finish (workgroup LDS, built once per workgroup): crc[k][b] = CRC-32 (reflected 0xedb88320)
+// of byte b followed by k zero bytes ("slicing by 4"), scr[s] = the next 32 scrambler bits from LFSR state s.
+struct FinishTables { uint32_t crc[4][256]; uint32_t scr[128]; };
+
+__device__ __forceinline__ void build_finish_tables(FinishTables& ft)
 {
-    uint32_t w0 = db[0];
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+        uint32_t c = (uint32_t)e;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+        ft.crc[0][e] = c;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) {
+        uint32_t c = ft.crc[0][e];
+        for (int k = 1; k < 4; k++) { c = (c >> 8) ^ ft.crc[0][c & 0xffu]; ft.crc[k][e] = c; }
+    }
+    for (int e = threadIdx.x; e < 128; e += blockDim.x) {
+        int state = e;
+        uint32_t w = 0;
+        for (int k = 0; k < 32; k++) {
+            const int fb = ((state >> 6) ^ (state >> 3)) & 1;
+            state = ((state << 1) & 0x7e) | fb;
+            w |= (uint32_t)fb << k;
+        }
+        ft.scr[e] = w;
+    }
+    __syncthreads();
+}
+
+// descramble (x^7+x^4+1, state from the first 7 decoded bits), bytes, CRC-32 of one frame; db = its decoded words
+// (stride 128 dwords, two spare words behind the last one).  Four PSDU bytes per iteration: the 32 decoded bits from
+// position 16 + 32 k on (a funnel shift of two decoded words), the 32 scrambler bits from the table (the state after
+// them is their last seven, reversed), CRC by four table look-ups.  Bytes leave four at a time when the row is
+// dword-aligned (wave-uniform `dword_ok`).
+__device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, int psdu_len, uint8_t* __restrict__ psdu,
+                                             bool dword_ok, wifirx_frame* __restrict__ rec, uint32_t flags,
+                                             const FinishTables& ft)
+{
+    uint32_t cur = db[0];
     int state = 0;
 #pragma unroll
-    for (int i = 0; i < 7; i++) state |= (int)((w0 >> i) & 1) << (6 - i);
+    for (int i = 0; i < 7; i++) state |= (int)((cur >> i) & 1) << (6 - i);
     // positions 7..15 belong to the SERVICE field: advance the scrambler
+#pragma unroll
     for (int i = 7; i < 16; i++) {
         int fb = ((state >> 6) ^ (state >> 3)) & 1;
         state = ((state << 1) & 0x7e) | fb;
     }
     uint32_t crc = 0xffffffffu;
-    uint32_t cur = w0, nxt = db[128];
-    int wi = 0;
-    uint32_t quad = 0;
-    for (int b = 0; b < psdu_len; b++) {
-        uint32_t byte = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = 16 + 8 * b + k;
-            if ((i >> 5) != wi) { wi = i >> 5; cur = nxt; nxt = db[(size_t)(wi + 1) * 128]; }
-            const uint32_t fb = (uint32_t)(((state >> 6) ^ (state >> 3)) & 1);
-            state = ((state << 1) & 0x7e) | (int)fb;
-            const uint32_t d = ((cur >> (i & 31)) & 1u) ^ fb;
-            byte |= d << k;
-            crc = crc32_bit(crc, d);
-        }
-        if (dword_ok) {
-            quad |= byte << (8 * (b & 3));
-            if ((b & 3) == 3) { *reinterpret_cast<uint32_t*>(psdu + b - 3) = quad; quad = 0; }
-            else if (b == psdu_len - 1) { for (int k = 0; k <= (b & 3); k++) psdu[b - (b & 3) + k] = (uint8_t)(quad >> (8 * k)); }
-        } else {
+    uint32_t nxt = db[128];
+    const int n_words = psdu_len >> 2;
+    for (int k = 0; k < n_words; k++) {
+        const uint32_t nn = db[(size_t)(k + 2) * 128];                     // spare words behind the last one keep this in range
+        const uint32_t sc = ft.scr[state];
+        state = (int)(__builtin_bitreverse32(sc) & 0x7fu);
+        const uint32_t d = __builtin_amdgcn_alignbit(nxt, cur, 16) ^ sc;    // positions 16 + 32 k .. + 31, descrambled
+        cur = nxt; nxt = nn;
+        if (dword_ok) *reinterpret_cast<uint32_t*>(psdu + 4 * k) = d;
+        else { psdu[4 * k] = (uint8_t)d; psdu[4 * k + 1] = (uint8_t)(d >> 8); psdu[4 * k + 2] = (uint8_t)(d >> 16); psdu[4 * k + 3] = (uint8_t)(d >> 24); }
+        const uint32_t x = crc ^ d;
+        crc = ft.crc[3][x & 0xffu] ^ ft.crc[2][(x >> 8) & 0xffu] ^ ft.crc[1][(x >> 16) & 0xffu] ^ ft.crc[0][x >> 24];
+    }
+    {   // the last one to three bytes
+        const uint32_t sc = ft.scr[state];
+        const uint32_t d = __builtin_amdgcn_alignbit(nxt, cur, 16) ^ sc;
+        for (int b = 4 * n_words; b < psdu_len; b++) {
+            const uint32_t byte = (d >> (8 * (b & 3))) & 0xffu;
             psdu[b] = (uint8_t)byte;
+            crc = (crc >> 8) ^ ft.crc[0][(crc ^ byte) & 0xffu];
         }
     }
     crc = ~crc;
@@ -293,6 +326,8 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                    uint32_t frames_per_wave, const uint64_t* __restrict__ masks_all)
 {
     __shared__ uint64_t lds_all[4][WR_DEC_LDS_WORDS];
+    __shared__ FinishTables ft;
+    build_finish_tables(ft);
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * 4 + wv;
@@ -447,7 +482,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
             if (n_data[h] > 0) {                               // the record is re-read: nothing of it was kept in registers
                 const uint32_t slot = base + (h ? fA : 0u) + lane;
                 finish_frame(dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
-                             ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags);
+                             ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags, ft);
             }
         }
     }
