@@ -440,24 +440,32 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
         }
         __threadfence_block();
         // ---- traceback of both frames: 32 decoded bits per word, words stored [word][A/B][lane].  The survivor
-        //      row of a step does not depend on the path (only the piece picked from it does), so sixteen rows are
-        //      loaded ahead of the sixteen dependent state updates: one memory round trip per sixteen steps ----
+        //      row of a step does not depend on the path (only the piece picked from it does), so the rows are
+        //      loaded ahead of the dependent state updates.
+        //      Fast form, when both frames of every lane run the full n_max steps: blocks of 96 steps = three whole
+        //      words.  Before step t the state holds the decoded bits u_t .. u_(t-5) in its bits 0..5, so the bits
+        //      leave six at a time (one bit reversal and one shift-or at a compile-time offset per six steps), and a
+        //      step is the survivor-bit pick plus two instructions.
+        //      General form (frames of different lengths in the wave; the steps above the last multiple of 96): one
+        //      decoded bit per step, every access predicated on the frame's own length. ----
         {
             int st0 = best[0], st1 = best[1];
             uint32_t word0 = 0, word1 = 0;
-            for (int t1 = n_max - 1; t1 >= 0; t1 -= 16) {
+            const bool uni = __all(n_data[0] == n_max && n_data[1] == n_max);
+            const int n_fast = uni ? (n_max / 96) * 96 : 0;
+            for (int t1 = n_max - 1; t1 >= n_fast; t1 -= 16) {
                 uint4 rows[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int t = t1 - k;
                     rows[k] = make_uint4(0u, 0u, 0u, 0u);
-                    if (t >= 0 && (t < n_data[0] || t < n_data[1]))
+                    if (t >= n_fast && (t < n_data[0] || t < n_data[1]))
                         rows[k] = *reinterpret_cast<const uint4*>(surv + ((size_t)t * 64 + lane) * 4);
                 }
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int t = t1 - k;
-                    const bool mine0 = t >= 0 && t < n_data[0], mine1 = t >= 0 && t < n_data[1];
+                    const bool mine0 = t >= n_fast && t < n_data[0], mine1 = t >= n_fast && t < n_data[1];
                     const int i0 = st0 >> 4, i1 = st1 >> 4;
                     const uint32_t p0 = i0 == 0 ? rows[k].x : i0 == 1 ? rows[k].y : i0 == 2 ? rows[k].z : rows[k].w;
                     const uint32_t p1 = i1 == 0 ? rows[k].x : i1 == 1 ? rows[k].y : i1 == 2 ? rows[k].z : rows[k].w;
@@ -472,6 +480,40 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                         st1 = (st1 >> 1) | (int)(h1 << 5);
                         if ((t & 31) == 0) { dbits[(size_t)(t >> 5) * 128 + 64 + lane] = word1; word1 = 0; }
                     }
+                }
+            }
+            for (int blk = n_fast / 96 - 1; blk >= 0; blk--) {
+                uint32_t a0[3] = { 0u, 0u, 0u }, a1[3] = { 0u, 0u, 0u };
+                const uint32_t* srow = surv + ((size_t)(blk * 96) * 64 + lane) * 4;
+#pragma unroll
+                for (int sub = 7; sub >= 0; sub--) {
+                    uint4 rows[12];
+#pragma unroll
+                    for (int k = 0; k < 12; k++) rows[k] = *reinterpret_cast<const uint4*>(srow + (size_t)(sub * 12 + k) * 256);
+#pragma unroll
+                    for (int gg = 1; gg >= 0; gg--) {
+                        const int off = 6 * (2 * sub + gg), w = off >> 5, o = off & 31;      // compile-time after unrolling
+                        const uint32_t v0 = __builtin_bitreverse32((uint32_t)st0) >> 26, v1 = __builtin_bitreverse32((uint32_t)st1) >> 26;
+                        a0[w] |= v0 << o;
+                        a1[w] |= v1 << o;
+                        if (o > 26) { a0[w + 1] |= v0 >> (32 - o); a1[w + 1] |= v1 >> (32 - o); }
+#pragma unroll
+                        for (int q = 5; q >= 0; q--) {
+                            const uint4 r = rows[6 * gg + q];
+                            const uint32_t l0 = (st0 & 16) ? r.y : r.x, u0 = (st0 & 16) ? r.w : r.z, p0 = (st0 & 32) ? u0 : l0;
+                            const uint32_t l1 = (st1 & 16) ? r.y : r.x, u1 = (st1 & 16) ? r.w : r.z, p1 = (st1 & 32) ? u1 : l1;
+                            const uint32_t h0 = __builtin_amdgcn_ubfe(p0, (uint32_t)((7 - st0) & 15), 1u);
+                            const uint32_t h1 = __builtin_amdgcn_ubfe(p1, (uint32_t)(16 + ((7 - st1) & 15)), 1u);
+                            st0 = (st0 >> 1) | (int)(h0 << 5);
+                            st1 = (st1 >> 1) | (int)(h1 << 5);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // keep the next twelve rows' loads behind these steps (registers)
+                }
+#pragma unroll
+                for (int w = 0; w < 3; w++) {
+                    dbits[(size_t)(blk * 3 + w) * 128 + lane] = a0[w];
+                    dbits[(size_t)(blk * 3 + w) * 128 + 64 + lane] = a1[w];
                 }
             }
         }

@@ -63,3 +63,27 @@ def test_decode_mac_bit_exact(capi, orc, encoding, snr, decode_path):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize("encoding,plen,snr", [(2, 294, 25.0), (2, 294, 5.0), (0, 60, 25.0), (0, 60, 6.0), (7, 294, 19.5), (5, 100, 13.0)])
+def test_decode_mac_full_waves(capi, orc, monkeypatch, encoding, plen, snr):
+    """The throughput decoder with all 128 frame positions of a wave filled (WIFIRX_DECODE_FPW: as in the 1M-frame
+    batches): its uniform traceback (blocks of 96 steps, six decoded bits at a time; trellis lengths with and without a
+    remainder mod 96) and, in the last wave, the predicated one -- byte for byte the oracle's PSDUs, also where the
+    channel leaves bit errors."""
+    monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "0")
+    monkeypatch.setenv("WIFIRX_DECODE_FPW", "128")
+    n = 300                                                   # two full waves + one with 44 frames
+    iq, slot_len, tx = make_slots(n, encoding, psdu_len=plen, snr_db=snr, seed=200 + encoding)
+    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=0)
+    r = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=320)
+    rx.close()
+    prm = orc.make_params(max_sym=tx.n_sym)
+    o = orc.demod_batch(iq, slot_len, prm, n_threads=8)
+    opsdu = orc.decode_batch(o["frames"], o["idx"], prm, psdu_stride=320, n_threads=8)
+    assert np.array_equal(r["frames"], o["frames"])
+    dec = (o["frames"]["flags"] & orc.F_DECODED) != 0
+    assert dec.sum() > 20
+    assert np.array_equal(r["psdu"][dec][:, :plen], opsdu[dec][:, :plen])
+    if snr >= 25:
+        assert ((o["frames"]["flags"] & orc.F_CRC_OK) != 0).all() and np.array_equal(r["psdu"][:, :plen], tx.psdu)
