@@ -496,9 +496,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     const double bw = prm.bandwidth, fc = prm.frequency;
     const double two_pi = 2 * 3.14159265358979323846;
     const double tag = (double)cfo_c - (double)cfo_f;
-    const double eps0 = tag * bw / (two_pi * fc);
-    const double er_scale = bw / (two_pi * fc * 80);
-    double d_er = 0.0;
+    // spec rule 9: the control chain of the sampling-offset compensation in float32 (formed once in double, rounded)
+    const float eps0 = (float)(tag * bw / (two_pi * fc));
+    const float er_scale = (float)(bw / (two_pi * fc * 80));
+    float d_er = 0.0f;
     // total derotation as an exact integer phase: Qp = 2^-62 quarter turns per sample; sample m has phase Qp*m
     // mod 2^64.  `ph` holds the phase of this lane's first sample of the current symbol and advances by Qp*80
     // (Qp*64 after the first long training symbol) -- two integer adds per symbol instead of a double product.
@@ -630,9 +631,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 
         // (1) sampling offset (spec rule 9)
         {
-            // upstream's double chain 2 pi s 80 (eps0 + d_er) / 64, float per bin; the factor that depends on s
-            // alone comes from a table (the division by 64 is exact, so it commutes with the product)
-            const float kf = (float)(WR_T4_64[s] * (eps0 + d_er));
+            // upstream: 2 pi s 80 (eps0 + d_er) / 64 in double; spec: the factor that depends on s alone comes from a
+            // float32 table, eps0 and d_er are float32
+            const float kf = WR_T4_64F[s] * (eps0 + d_er);
             // b = phasor of bin r + 16; lane 0 of the row holds exp(-j kf 16), whose conjugate is the step
             c32 b;
             sp_sincos_small(kf * (float)(r - 16), b.im, b.re);
@@ -664,13 +665,13 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             cur2 = cflip(X39, sgn);
             cur3 = cflip(X53, sgn ^ 0x80000000u);
         }
-        double er = 0.0;
+        float er = 0.0f;
         if (s >= 2) {
             const float2 q0 = pvl[0], q1 = pvl[1], q2 = pvl[2], q3 = pvl[3];
             const c32 prev0 = { q0.x, q0.y }, prev1 = { q1.x, q1.y }, prev2 = { q2.x, q2.y }, prev3 = { q3.x, q3.y };
             c32 acc = cadd(cadd(cadd(sp_conj_mul(prev0, cur0), sp_conj_mul(prev1, cur1)),
                                 sp_conj_mul(prev2, cur2)), sp_conj_mul(prev3, cur3));
-            er = (double)sp_atan2(acc.im, acc.re) * er_scale;
+            er = sp_atan2(acc.im, acc.re) * er_scale;
         }
         __builtin_amdgcn_wave_barrier();
         if (r == 0) {
@@ -689,10 +690,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             for (int j = 0; j < 4; j++) X[j] = sp_rot(X[j], sn, cs);
         }
         // (5) IIR
-        if (s >= 2) {
-            double alpha = 0.1;
-            d_er = (1 - alpha) * d_er + alpha * er;
-        }
+        if (s >= 2) d_er = fma_(0.1f, er, 0.9f * d_er);
         // (6a) COMB: this symbol's pilots (polarity removed) are the channel at bins 11, 25, 39, 53, their mean stands at
         //      the band edges (bins 0 and 64); linear interpolation, then d_H = 0.8 d_H + 0.2 H (d_H = H at s = 0)
         if (COMB) {

@@ -35,6 +35,7 @@
 #include <string.h>
 
 #include "wifirx.h"
+#define WR_WANT_T4_TABLE
 #include "wifirx_tables.h"
 
 #define ORC_MATH_SPEC 0
@@ -684,6 +685,11 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     const double tag = (double)cfo_c - (double)cfo_f;          /* sync_long's wifi_start tag */
     const double eps0 = tag * bw / (2 * M_PI * fc);
     double d_er = 0.0;
+    /* Spec rule 9: the control chain of the sampling-offset compensation in float32 -- eps0 and the scale of the residual
+     * estimate are formed once per frame in double and rounded; the IIR state, its input and the angle factor are float.
+     * (Upstream keeps doubles; the distance to that is measured: profiles/r02_spec_vs_libm.json.) */
+    const float eps0_f = (float)eps0, er_scale_f = (float)(bw / (2 * M_PI * fc * 80));
+    float d_er_f = 0.0f, er_f = 0.0f;
     const double theta_d = (double)cfo_f - (double)cfo_c;       /* total derotation, rad/sample */
     /* ... as an integer phase increment: 2^-62 quarter turns per sample */
     const uint64_t Qp = (uint64_t)(int64_t)rint(theta_d * WR_TWO_OVER_PI_D * 4611686018427387904.0);
@@ -739,7 +745,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
         if (spec) {
             /* Spec rule 9: b(r) = exp(j kf (r - 16)) is the phasor of bin r + 16; the step between bins 16 apart is
              * conj(b(0)) = exp(j kf 16); bins r, r + 32, r + 48 take b(r) b(0), b(r) step, (b(r) step) step. */
-            const float kf = (float)(t4 * (1.0 / 64));      /* the double chain of upstream up to here, float per bin */
+            const float kf = WR_T4_64F[s] * (eps0_f + d_er_f);      /* T4F[s] = float(2 pi s 80 / 64) */
             float s0, c0;
             sp_sincos(kf * (float)(0 - 16), &s0, &c0);
             const c32 b0 = { c0, s0 }, step = { c0, -s0 };
@@ -793,6 +799,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             }
             float erf = spec ? sp_atan2(acc.im, acc.re) : atan2f(acc.im, acc.re);
             er = (double)erf * (bw / (2 * M_PI * fc * 80));
+            er_f = erf * er_scale_f;
         }
         memcpy(prev, cur, sizeof prev);
         /* (4) derotate by -beta.  Spec (section 4.10): exp(-j beta) = conj(S) * (1/|S|) with a correctly rounded sqrt and
@@ -820,6 +827,7 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
         if (s >= 2) {
             double alpha = 0.1;
             d_er = (1 - alpha) * d_er + alpha * er;
+            d_er_f = fmaf(0.1f, er_f, 0.9f * d_er_f);
         }
                 /* (6a) COMB (ieee802_11.COMB; definition: DESIGN.md section 4.11 -- upstream's source is absent, restated from
          * the published comb-pilot scheme): the four pilots of THIS symbol, polarity removed, are the channel at bins

@@ -134,6 +134,7 @@ int main(int argc, char** argv)
     const char* names[6] = { "loads+stores+preamble", "loads+stores", "loads only", "stores only",
                              "loads+line stores+preamble", "loads+line stores" };
     const int cfg[6][3] = { { 1, 1, 1 }, { 0, 1, 1 }, { 0, 1, 0 }, { 0, 0, 1 }, { 1, 1, 2 }, { 0, 1, 2 } };
+    float res[6];
     for (int c = 0; c < 6; c++) {
         float best = 1e9f;
         for (int it = 0; it < 5; it++) {
@@ -148,7 +149,13 @@ int main(int argc, char** argv)
         const double rd = (double)n_slots * ((cfg[c][1] ? 53.0 * 64 * 8 : 0) + (cfg[c][0] ? 640.0 * 8 : 0));
         const double wr = cfg[c][2] ? (double)n_slots * n_sym * 48 * 9 : 0;
         printf("%-28s %8.3f ms   %.1f GB moved by lanes -> %.2f TB/s\n", names[c], best, (rd + wr) / 1e9, (rd + wr) / best / 1e9);
+        res[c] = best;
     }
+    // one JSON line for profiles/*_mem_floor.json (bench.py quotes combined_ms)
+    printf("{\"tool\": \"tools/mem_floor.hip\", \"n_slots\": %u, \"combined_ms\": %.3f, \"symbols_only_ms\": %.3f, "
+           "\"loads_only_ms\": %.3f, \"stores_only_ms\": %.3f, \"what\": \"the global loads and stores of demod_batch_kernel on "
+           "config 2 (same addresses, order and wave organisation), no arithmetic\"}\n",
+           n_slots, res[0], res[1], res[2], res[3]);
     for (int mode = 0; mode < 6; mode++) {
         float best = 1e9f;
         for (int it = 0; it < 4; it++) {
