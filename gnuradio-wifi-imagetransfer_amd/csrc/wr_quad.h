@@ -512,6 +512,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     }
     unsigned long long ph = Qp * (unsigned long long)(unsigned)(fs + r);
     const unsigned long long q80 = Qp * 80ull;
+    const float rp_qpsk = 1.0f / fma_(WR_LEVEL_QPSK, WR_LEVEL_QPSK, WR_LEVEL_QPSK * WR_LEVEL_QPSK);     // LMS / STA: 1 / |QPSK point|^2
     int n_sym = 0, n_bpsc = 1, n_out = 0, enc = 0, psdu_len = 0;
     bool have_signal = false, want_llr = false;
     float snr = 0.0f;
@@ -753,6 +754,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             c32 Y[4];
             int carrier[4];
             c32 HU[4];                                   // STA: this symbol's per-bin estimates of my bins
+            const bool const_mag = (LMS || STA) && __all(s == 2 || n_bpsc <= 2);      // wave-uniform
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 carrier[j] = carrier0[j];
@@ -770,7 +772,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                         if (LMS || STA) {
                             const int nbl = (s == 2) ? 1 : n_bpsc;
                             const c32 pt = point_of(decide(Y[j], nbl), nbl);
-                            const float rp = 1.0f / fma_(pt.im, pt.im, pt.re * pt.re);
+                            // 1 / |point|^2: BPSK and QPSK points all have one magnitude, the quotient is formed once per wave
+                            // (same value); the wave divides per bin only when a row carries 16- or 64-QAM
+                            float rp;
+                            if (const_mag) rp = nbl == 1 ? 1.0f : rp_qpsk;
+                            else           rp = 1.0f / fma_(pt.im, pt.im, pt.re * pt.re);
                             const float tr = fma_(X[j].im, pt.im, X[j].re * pt.re) * rp;
                             const float ti = fma_(X[j].im, pt.re, -(X[j].re * pt.im)) * rp;
                             if (LMS && act) Hl[64 * j] = make_float2(0.5f * g0.x + 0.5f * tr, 0.5f * g0.y + 0.5f * ti);
