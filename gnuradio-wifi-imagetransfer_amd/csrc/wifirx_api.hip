@@ -51,6 +51,7 @@ struct wifirx_handle {
     void*  stage_psdu = nullptr;    size_t stage_psdu_bytes = 0;
     void*  stage_csi = nullptr;     size_t stage_csi_bytes = 0;
     void*  stage_stats = nullptr;   size_t stage_stats_bytes = 0;
+    void*  stage_off = nullptr;     size_t stage_off_bytes = 0;      // slot offsets of wifirx_demod_batch_v
 
     // decode workspace
     void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;
@@ -198,7 +199,7 @@ int wifirx_destroy(wifirx_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (float2* r : h->ring) if (r) (void)hipHostFree(r);
-    void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi, h->stage_stats, h->s_stats,
+    void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi, h->stage_stats, h->stage_off, h->s_stats,
                      h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx,
                      h->s_car, h->s_psdu, h->s_csi };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -318,8 +319,31 @@ static int check_batch(wifirx_handle* h, uint32_t slot_len, uint32_t n_slots, co
     return WIFIRX_OK;
 }
 
+static int demod_batch_impl(wifirx_handle* h, const float* iq, int iq_on_device, uint32_t slot_len,
+                            uint32_t n_slots, const wifirx_out* out, const uint64_t* slot_off_host);
+
 int wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device, uint32_t slot_len,
                        uint32_t n_slots, const wifirx_out* out)
+{
+    return demod_batch_impl(h, iq, iq_on_device, slot_len, n_slots, out, nullptr);
+}
+
+int wifirx_demod_batch_v(wifirx_handle* h, const float* iq, int iq_on_device, const uint64_t* slot_off,
+                         uint32_t n_slots, const wifirx_out* out)
+{
+    if (!h) return WIFIRX_EINVAL;
+    if (!slot_off) return fail(h, WIFIRX_EINVAL, "slot_off is null");
+    uint64_t longest = 1;
+    for (uint32_t k = 0; k < n_slots; k++) {
+        if (slot_off[k + 1] < slot_off[k]) return fail(h, WIFIRX_EINVAL, "slot_off must not decrease");
+        if (slot_off[k + 1] - slot_off[k] > 0x7fffffffu) return fail(h, WIFIRX_ERANGE, "slot longer than 2^31 - 1 samples");
+        longest = std::max<uint64_t>(longest, slot_off[k + 1] - slot_off[k]);
+    }
+    return demod_batch_impl(h, iq, iq_on_device, (uint32_t)longest, n_slots, out, slot_off);
+}
+
+static int demod_batch_impl(wifirx_handle* h, const float* iq, int iq_on_device, uint32_t slot_len,
+                            uint32_t n_slots, const wifirx_out* out, const uint64_t* slot_off_host)
 {
     int rc = check_batch(h, slot_len, n_slots, out);
     if (rc) return rc;
@@ -327,7 +351,14 @@ int wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device, uint
     if (n_slots == 0) return WIFIRX_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     const wr::DemodParams prm = params_of(h);
-    const size_t n_iq = (size_t)slot_len * n_slots;
+    const size_t n_iq = slot_off_host ? (size_t)(slot_off_host[n_slots] - slot_off_host[0]) + (size_t)slot_off_host[0]
+                                      : (size_t)slot_len * n_slots;
+    const uint64_t* d_off = nullptr;
+    if (slot_off_host) {
+        if ((rc = ensure(h, &h->stage_off, &h->stage_off_bytes, ((size_t)n_slots + 1) * sizeof(uint64_t)))) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->stage_off, slot_off_host, ((size_t)n_slots + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+        d_off = reinterpret_cast<const uint64_t*>(h->stage_off);
+    }
     const size_t idx_n = (size_t)n_slots * h->cfg.max_sym * 48;
     const float2* d_iq = reinterpret_cast<const float2*>(iq);
     if (!iq_on_device) {
@@ -370,7 +401,7 @@ int wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device, uint
         }
     }
     const wr::DemodOut dout = { d_fr, d_idx, d_llr, d_car, d_csi, d_stats };
-    HIP_TRY(h, wr_launch_demod_batch(h->stream, d_iq, slot_len, n_slots, &prm, &dout));
+    HIP_TRY(h, wr_launch_demod_batch(h->stream, d_iq, slot_len, n_slots, &prm, &dout, d_off));
     h->stats.samples_in += n_iq;
     if (!out->on_device) {
         HIP_TRY(h, hipMemcpyAsync(out->frames, d_fr, n_slots * sizeof(wifirx_frame), hipMemcpyDeviceToHost, h->stream));
@@ -409,7 +440,7 @@ int wifirx_time_demod(wifirx_handle* h, const float* iq_dev, uint32_t slot_len, 
         HIP_TRY(h, hipEventRecord(ev.e0, h->stream));
         const wr::DemodOut dout = { out->frames, out->idx, out->llr, reinterpret_cast<float2*>(out->carrier),
                                     reinterpret_cast<float2*>(out->csi), reinterpret_cast<float4*>(out->sym_stats) };
-        HIP_TRY(h, wr_launch_demod_batch(h->stream, reinterpret_cast<const float2*>(iq_dev), slot_len, n_slots, &prm, &dout));
+        HIP_TRY(h, wr_launch_demod_batch(h->stream, reinterpret_cast<const float2*>(iq_dev), slot_len, n_slots, &prm, &dout, nullptr));
         HIP_TRY(h, hipEventRecord(ev.e1, h->stream));
         HIP_TRY(h, hipEventSynchronize(ev.e1));
         float ms = 0;

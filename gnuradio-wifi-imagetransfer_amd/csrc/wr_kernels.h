@@ -55,7 +55,7 @@ struct StreamTrig {
 
 extern "C" {
 hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot_len, uint32_t n_slots,
-                                 const wr::DemodParams* prm, const wr::DemodOut* out);
+                                 const wr::DemodParams* prm, const wr::DemodOut* out, const uint64_t* slot_off);
 hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_templates, uint32_t frame_len,
                            float2* slots, uint32_t slot_len, uint32_t n_slots, uint32_t lead, float gain,
                            float noise, float cfo_max, uint64_t seed, float* cfo_out);

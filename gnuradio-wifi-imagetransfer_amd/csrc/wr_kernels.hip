@@ -156,7 +156,7 @@ __device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n
 template <int EQ>
 __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ == WIFIRX_EQ_STA ? WR_DEMOD_WAVES_PER_SIMD_STA : WR_DEMOD_WAVES_PER_SIMD)
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
-                        DemodParams prm, DemodOut out)
+                        DemodParams prm, DemodOut out, const uint64_t* __restrict__ slot_off)
 {
     __shared__ __attribute__((aligned(16))) float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
     const int lane = threadIdx.x & 63;
@@ -174,7 +174,11 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
         for (int f = 0; f < 4; f++) {
             const uint32_t slot = slot0 + f;
             const bool has = slot < n_slots;                // wave-uniform
-            pf[f] = { iq + (size_t)(has ? slot : slot0) * slot_len, has ? (long)slot_len : 0l, -1, 0, 0.0f, false, has ? (long)slot : -1l };
+            // uniform slots, or slot k = samples [slot_off[k], slot_off[k+1]) of iq (wifirx_demod_batch_v)
+            const uint32_t sk = has ? slot : slot0;
+            const size_t off = slot_off ? (size_t)slot_off[sk] : (size_t)sk * slot_len;
+            const long len = slot_off ? (long)(slot_off[sk + 1] - slot_off[sk]) : (long)slot_len;
+            pf[f] = { iq + off, has ? len : 0l, -1, 0, 0.0f, false, has ? (long)slot : -1l };
             detect_load(pf[f].x, pf[f].n_samp, lane, da[f]);
         }
 #pragma unroll
@@ -184,7 +188,7 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
             pf[f].t = t;
             if (t >= 0) {
                 pf[f].cfo_c = sp_atan2(A_t.im, A_t.re) / 16.0f;
-                long L = (long)slot_len - (t - 16);
+                long L = pf[f].n_samp - (t - 16);
                 if (L > WIFIRX_MAX_SAMPLES) L = WIFIRX_MAX_SAMPLES;
                 pf[f].L = L;
                 pf[f].search = L >= WIFIRX_SYNC_LENGTH + 63;
@@ -276,15 +280,16 @@ void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const Stream
 }  // namespace wr
 
 extern "C" hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot_len,
-                                            uint32_t n_slots, const wr::DemodParams* prm, const wr::DemodOut* out)
+                                            uint32_t n_slots, const wr::DemodParams* prm, const wr::DemodOut* out,
+                                            const uint64_t* slot_off)
 {
     if (n_slots == 0) return hipSuccess;
     dim3 grid((n_slots + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
     switch (prm->chan_est) {
-    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out); break;
-    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out); break;
-    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out); break;
-    default:             hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out); break;
+    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out, slot_off); break;
+    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out, slot_off); break;
+    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out, slot_off); break;
+    default:             hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out, slot_off); break;
     }
     return hipGetLastError();
 }

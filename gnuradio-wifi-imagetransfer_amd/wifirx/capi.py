@@ -31,7 +31,7 @@ EXPORTS = [
     "wifirx_create", "wifirx_destroy", "wifirx_last_error", "wifirx_abi_version", "wifirx_set_param",
     "wifirx_get_stats", "wifirx_demod_batch", "wifirx_decode_batch", "wifirx_push", "wifirx_poll", "wifirx_poll_csi",
     "wifirx_sync", "wifirx_stream", "wifirx_synth_slots", "wifirx_dev_alloc", "wifirx_dev_free",
-    "wifirx_memcpy_h2d", "wifirx_memcpy_d2h", "wifirx_time_demod", "wifirx_poll_ex",
+    "wifirx_memcpy_h2d", "wifirx_memcpy_d2h", "wifirx_time_demod", "wifirx_poll_ex", "wifirx_demod_batch_v",
 ]
 
 
@@ -79,6 +79,7 @@ _lib.wifirx_set_param.argtypes = [C.c_void_p, C.c_int, C.c_double]
 _lib.wifirx_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
 _lib.wifirx_demod_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(Out)]
 _lib.wifirx_decode_batch.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Out)]
+_lib.wifirx_demod_batch_v.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(Out)]
 _lib.wifirx_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 _lib.wifirx_poll.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                              C.c_uint32, C.POINTER(C.c_uint32)]
@@ -215,6 +216,21 @@ class WifiRx:
         finally:
             d_iq.free()
             self.free_out(dev)
+
+    def demod_batch_var(self, iq: np.ndarray, slot_off) -> dict:
+        """batch mode over slots of unequal length: slot k = iq[slot_off[k] : slot_off[k+1]] (host buffers)"""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
+        off = np.ascontiguousarray(slot_off, dtype=np.uint64)
+        n_slots = off.size - 1
+        assert n_slots >= 0 and int(off[-1]) <= iq.size
+        ms = self.cfg.max_sym
+        frames = np.zeros(n_slots, dtype=FRAME_DTYPE)
+        idx = np.zeros((n_slots, ms, 48), dtype=np.uint8)
+        llr = np.zeros((n_slots, ms * 48 * self.cfg.llr_bits), dtype=np.float32) if self.cfg.llr_bits else None
+        car = np.zeros((n_slots, ms, 48), dtype=np.complex64) if self.cfg.want_carrier else None
+        out = Out(_np_ptr(frames), _np_ptr(idx), _np_ptr(llr), _np_ptr(car), None, 0, 0, None, None)
+        self._check(_lib.wifirx_demod_batch_v(self._h, _np_ptr(iq), 0, _np_ptr(off), n_slots, C.byref(out)))
+        return dict(frames=frames, idx=idx, llr=llr, carrier=car)
 
     # -- batch mode, device buffers (the measured path) --
     def alloc_out(self, n_slots, psdu_stride=0, want_csi=False, want_stats=False) -> dict:

@@ -194,11 +194,15 @@ int  wifirx_get_stats(const wifirx_handle* h, wifirx_stats* st);
  * demodulated:  autocorrelation graph + sync_short + sync_long + fft_vcc + frame_equalizer
  * (gnu_radio/IRS_AP.py:268-269,271,273,276-285).  Asynchronous on the handle's stream when all
  * buffers are on the device; call wifirx_sync() before reading results.
- * Slots have ONE common length: there is no slot_off[] table of per-slot offsets (SURVEY.md 8(b) sketched one).
- * Recordings of unequal length are padded to the longest (trailing samples of a slot cost nothing: the kernel stops
- * reading a slot after its frame's last symbol) or go through stream mode (wifirx_push), which has no slot notion. */
+ * Slots of unequal length: wifirx_demod_batch_v. */
 int  wifirx_demod_batch(wifirx_handle* h, const float* iq, int iq_on_device,
                         uint32_t slot_len, uint32_t n_slots, const wifirx_out* out);
+
+/* The same over slots of unequal length (the slot_off[] form of SURVEY.md 8(b)): slot k is the samples
+ * [slot_off[k], slot_off[k+1]) of `iq`; slot_off is a HOST array of n_slots + 1 non-decreasing sample offsets (the
+ * library copies it to the device before the launch).  Output row k belongs to slot k; a slot may be empty. */
+int  wifirx_demod_batch_v(wifirx_handle* h, const float* iq, int iq_on_device, const uint64_t* slot_off,
+                          uint32_t n_slots, const wifirx_out* out);
 
 /* decode_mac over the hard decisions of a previous wifirx_demod_batch on the same buffers
  * (ieee802_11.decode_mac, gnu_radio/IRS_AP.py:272,291-292): de-interleave, de-puncture, Viterbi

@@ -107,3 +107,38 @@ def test_decode_with_unaligned_buffers(orc, decode_path):
     for b in (d_iq, d_fr, d_idx, d_psdu):
         b.free()
     rx.close()
+
+
+def test_slots_of_unequal_length(orc):
+    """wifirx_demod_batch_v (the slot_off[] form of SURVEY.md 8(b)): recordings of different lengths back to back, one
+    of them empty, one too short for a frame -- every slot equals the oracle's result for that slot alone."""
+    from wifirx import capi, txgen
+    rng = np.random.default_rng(3)
+    parts, refs = [], []
+    encs = [0, 2, 5, 7, 3, 6, 2, 4, 1]
+    for k, enc in enumerate(encs):
+        plen = int(rng.integers(40, 200))
+        tx = txgen.encode_psdus(txgen.make_psdus(1, plen, seed=40 + k), enc)
+        total = int(rng.integers(tx.samples.shape[1] + 100, tx.samples.shape[1] + 900))
+        parts.append(txgen.impair(tx.samples, 25.0, cfo=float(rng.uniform(-0.03, 0.03)), lead=int(rng.integers(20, 90)),
+                                  total=total, seed=k)[0])
+    parts.insert(3, np.zeros(0, np.complex64))                       # an empty slot
+    parts.insert(6, parts[0][:250].copy())                           # a slot shorter than the LTS search needs
+    off = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.uint64)
+    iq = np.concatenate(parts)
+    max_sym = 140
+    rx = capi.WifiRx(max_sym=max_sym, llr_bits=6, want_carrier=True)
+    r = rx.demod_batch_var(iq, off)
+    rx.close()
+    prm = orc.make_params(max_sym=max_sym, llr_bits=6)
+    n_ok = 0
+    for k, p in enumerate(parts):
+        if p.size == 0:
+            assert r["frames"]["flags"][k] == 0 and r["frames"]["trigger"][k] == -1
+            continue
+        o = orc.demod_batch(p, p.size, prm, want_eq=True)
+        assert np.array_equal(r["frames"][k:k + 1], o["frames"]), k
+        assert np.array_equal(r["idx"][k], o["idx"][0]) and np.array_equal(r["llr"][k], o["llr"][0]), k
+        assert np.array_equal(r["carrier"][k], o["eq"][0]), k
+        n_ok += int((o["frames"]["flags"][0] & orc.F_COMPLETE) != 0)
+    assert n_ok == len(encs)
