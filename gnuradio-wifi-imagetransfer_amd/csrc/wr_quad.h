@@ -246,10 +246,17 @@ __device__ __forceinline__ bool lts_peaks(const float (&cr)[10], int lane, int& 
         const float mag = fma_(ci[n], ci[n], cr[n] * cr[n]);
         km[n] = (holds_re && mag >= 0.0f) ? (int)__float_as_uint(mag) : -1;
     }
-    int top_off[4];
-    c32 top_val[4];
+    int top_off[4] = { -1, -1, -1, -1 };
+    c32 top_val[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
 #pragma unroll
     for (int r = 0; r < 4; r++) {
+        // The pair search below takes the first pair that is exactly 64 lags apart and looks no further; the pair
+        // (largest, second largest) comes first.  When those two are 64 apart -- every clean frame -- the third and
+        // fourth largest can never be looked at: their rounds are skipped (wave-uniform; same result by construction).
+        if (r == 2) {
+            const int d01 = top_off[0] > top_off[1] ? top_off[0] - top_off[1] : top_off[1] - top_off[0];
+            if (top_off[0] >= 0 && top_off[1] >= 0 && d01 == 64) break;
+        }
         int m = km[0];
 #pragma unroll
         for (int n = 1; n < 10; n++) m = km[n] > m ? km[n] : m;
