@@ -256,6 +256,7 @@ def main():
     # ---- the leg behind the hot path: decode_mac (+ RCCL all-gather of the PDUs), timed on its own ----
     pdu_leg = None
     if args.pdu_steps > 0:
+        pdu_step()                                # untimed: first-call allocations (survivor scratch), communicator set-up
         barrier()
         dec_ms, ag_ms = [], []
         t1 = time.perf_counter()

@@ -12,7 +12,8 @@
  * negative WIFIRX_E* code; nothing throws across the boundary; no global state: every call works
  * on a handle.  One handle = one stream of samples = one HIP stream; calls on one handle must be
  * serialised by the caller, different handles are independent (GNU Radio runs each block on its
- * own thread, so this matches the reference's threading).
+ * own thread, so this matches the reference's threading).  Stream mode with WIFIRX_P_STREAM_BATCH runs its
+ * device pipeline on a worker thread owned by the handle; that is internal and changes nothing of the above.
  *
  * There is NO CPU fallback in this library: wifirx_create() fails with WIFIRX_ENODEV when no
  * gfx950 device is usable.  The CPU restatement lives in oracle/ and is test infrastructure only.
