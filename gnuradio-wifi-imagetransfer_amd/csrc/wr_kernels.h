@@ -12,7 +12,7 @@
 #define WR_DEMOD_WAVES_PER_SIMD 4       // register budget of the demod kernels: 512/4 = 128 VGPRs
 #endif
 #ifndef WR_DEMOD_WAVES_PER_SIMD_STA
-#define WR_DEMOD_WAVES_PER_SIMD_STA 3   // STA alone runs faster with 168 registers (25.9 vs 28.8 ms on config 2: 19 spills at 128)
+#define WR_DEMOD_WAVES_PER_SIMD_STA 4   // (with its window sum free of per-term tests STA fits 128 registers too: 20.3 vs 24.2 ms at 3)
 #endif
 #define WR_STREAM_SPAN     16       // tiles of 64 samples one wave scans in stream-mode detection
 #define WR_DECODE_MAX_WAVES 4096    // waves of the decode kernel (grid-stride; each owns a scratch slice)

@@ -546,6 +546,16 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #pragma unroll
         for (int j = 0; j < 4; j++) { cw[j] = WR_COMB_W[r + 16 * j]; cu[j] = WR_COMB_U[r + 16 * j]; }
     }
+    float sta_inv[4] = { 0.0f, 0.0f, 0.0f, 0.0f };       // STA: float32 reciprocal of the number of used bins within +-2 of bin r + 16 j
+    if (STA) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int cnt = 0;
+#pragma unroll
+            for (int dk = -2; dk <= 2; dk++) { const int k = r + 16 * j + dk; cnt += (k >= 6 && k <= 58 && k != 32); }
+            sta_inv[j] = cnt == 3 ? 0x1.555556p-2f : cnt == 4 ? 0.25f : 0x1.99999ap-3f;     // 1/3, 1/4, 1/5
+        }
+    }
     int carrier0[4];                     // data carrier number 0..47 of bin r + 16 j, -1 for pilots / DC / guards
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -801,28 +811,27 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 if (r == 9)  HU[1] = cflip(X[1], sgn);
                 if (r == 7)  HU[2] = cflip(X[2], sgn);
                 if (r == 5)  HU[3] = cflip(X[3], sgn ^ 0x80000000u);
-                float2* hu = reinterpret_cast<float2*>(qlds) + 64 * row;
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int j = 0; j < 4; j++) hu[r + 16 * j] = make_float2(HU[j].re, HU[j].im);
+                // rows of 68 entries in the FFT's LDS area: the 64 bins with the unused ones written as zero, two zeros on
+                // either side -- the window sum then needs no per-term test (spec rule 11: zeros take part in the sum)
+                float2* hu = reinterpret_cast<float2*>(qlds) + 68 * row + 2;
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int i = r + 16 * j;
                     const bool usedj = (i >= 6 && i <= 58 && i != 32);
-                    c32 sum = { 0.0f, 0.0f };
-                    int cnt = 0;
+                    hu[i] = usedj ? make_float2(HU[j].re, HU[j].im) : make_float2(0.0f, 0.0f);
+                }
+                if (r < 2) { hu[r - 2] = make_float2(0.0f, 0.0f); hu[64 + r] = make_float2(0.0f, 0.0f); }
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int dk = -2; dk <= 2; dk++) {
-                        const int k = i + dk;
-                        const bool ok = (k >= 6 && k <= 58 && k != 32);
-                        const float2 v = hu[ok ? k : i];
-                        const c32 add = (cnt > 0) ? cadd(sum, c32{ v.x, v.y }) : c32{ v.x, v.y };
-                        if (ok) { sum = add; cnt++; }
-                    }
-                    const float inv = cnt == 3 ? 0x1.555556p-2f : cnt == 4 ? 0.25f : 0x1.99999ap-3f;     // 1/3, 1/4, 1/5 in float32
+                for (int j = 0; j < 4; j++) {
+                    const int i = r + 16 * j;
+                    const bool usedj = (i >= 6 && i <= 58 && i != 32);
+                    const float2 v0 = hu[i - 2], v1 = hu[i - 1], v2 = hu[i], v3 = hu[i + 1], v4 = hu[i + 2];
+                    const c32 sum = cadd(cadd(cadd(cadd(c32{ v0.x, v0.y }, c32{ v1.x, v1.y }), c32{ v2.x, v2.y }), c32{ v3.x, v3.y }),
+                                         c32{ v4.x, v4.y });
                     const float2 o = Hl[64 * j];
-                    if (act && usedj) Hl[64 * j] = make_float2(0.5f * o.x + 0.5f * (sum.re * inv), 0.5f * o.y + 0.5f * (sum.im * inv));
+                    if (act && usedj) Hl[64 * j] = make_float2(0.5f * o.x + 0.5f * (sum.re * sta_inv[j]), 0.5f * o.y + 0.5f * (sum.im * sta_inv[j]));
                 }
                 __builtin_amdgcn_wave_barrier();
             }

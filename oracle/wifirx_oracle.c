@@ -957,12 +957,14 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 c32 NH[64];
                 for (int i = 6; i <= 58; i++) {
                     if (i == 32) continue;
+                    /* the window sum takes the five bins i-2 .. i+2 in ascending order, an unused bin as +0 (spec rule 11) */
                     c32 sum = { 0.0f, 0.0f };
                     int cnt = 0;
                     for (int k = i - 2; k <= i + 2; k++) {
-                        if (k == 32 || k < 6 || k > 58) continue;
-                        sum = cnt ? cadd(sum, HU[k]) : HU[k];
-                        cnt++;
+                        const int used = !(k == 32 || k < 6 || k > 58);
+                        const c32 z = used ? HU[k] : (c32){ 0.0f, 0.0f };
+                        sum = (k == i - 2) ? z : cadd(sum, z);
+                        cnt += used;
                     }
                     /* the mean over 3, 4 or 5 bins: times the float32 reciprocal of the count */
                     const float inv = cnt == 3 ? 0x1.555556p-2f : cnt == 4 ? 0.25f : 0x1.99999ap-3f;
