@@ -81,6 +81,21 @@ __device__ __forceinline__ void sp_sincos_q(uint32_t p_hi, uint32_t p_lo, float&
     c = ((k + 1) & 2) ? -c0 : c0;
 }
 
+// 1/sqrt(v) for normal positive v: seed by halving the exponent, three Newton steps y <- y (1.5 - 0.5 v y^2)
+// (plain multiplies and fmas: bit-identical to the oracle's, relative error 1.3e-7; v_rsq_f32 would not be reproducible)
+__device__ __forceinline__ float sp_rsqrt(float v)
+{
+    float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(v) >> 1));
+    const float h = 0.5f * v;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float t = y * y;
+        const float u = fma_(-h, t, 1.5f);
+        y = y * u;
+    }
+    return y;
+}
+
 __device__ __forceinline__ float sp_atan2(float y, float x)
 {
     float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);

@@ -697,13 +697,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             pvl[2] = make_float2(cur2.re, cur2.im); pvl[3] = make_float2(cur3.re, cur3.im);
         }
         __builtin_amdgcn_wave_barrier();
-        // (4) common phase: exp(-j beta) = conj(S)/|S| (spec section 4.9)
+        // (4) common phase: exp(-j beta) = conj(S) rsqrt(|S|^2) (spec rule 10)
         {
             float n2 = fma_(S.im, S.im, S.re * S.re);
-            float nn = __builtin_sqrtf(n2);
-            float inv = 1.0f / nn;
-            float cs = (nn > 0.0f) ? S.re * inv : 1.0f;
-            float sn = (nn > 0.0f) ? -(S.im * inv) : 0.0f;
+            float inv = sp_rsqrt(n2);
+            float cs = (n2 > 0.0f) ? S.re * inv : 1.0f;
+            float sn = (n2 > 0.0f) ? -(S.im * inv) : 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; j++) X[j] = sp_rot(X[j], sn, cs);
         }

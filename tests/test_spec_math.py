@@ -1,5 +1,6 @@
 """Accuracy of the spec's own math routines (they replace libm so that CPU and GPU agree bit for bit)."""
 import numpy as np
+import pytest
 
 
 def test_sincos_accuracy(orc):
@@ -33,6 +34,18 @@ def test_log2_accuracy(orc):
     ref = np.log2(v.astype(np.float64))
     assert np.max(np.abs(r - ref)) < 3e-6
     assert np.max(np.abs(r - ref) / np.maximum(1, np.abs(ref))) < 4e-7
+
+
+def test_rsqrt_accuracy(orc):
+    """spec rule 10: three Newton steps from the exponent-halving seed"""
+    rng = np.random.default_rng(4)
+    # every mantissa of two adjacent binades (the seed's error has period two in the exponent) + a wide range
+    m = (np.arange(1 << 24, dtype=np.uint32) | np.uint32(0x3F000000)).view(np.float32)
+    v = np.concatenate([m, np.exp(rng.uniform(-80, 80, 1 << 20)).astype(np.float32)])
+    r = orc.rsqrt(v).astype(np.float64)
+    rel = np.abs(r * np.sqrt(v.astype(np.float64)) - 1.0)
+    assert rel.max() < 1.5e-7, rel.max()
+    assert orc.rsqrt(np.float32([1.0, 4.0, 0.25])).tolist() == pytest.approx([1.0, 0.5, 2.0], rel=2e-7)
 
 
 def test_fft64_spec_matches_numpy_and_libm_mode(orc):
