@@ -51,12 +51,13 @@ struct wifirx_handle {
     void*  stage_psdu = nullptr;    size_t stage_psdu_bytes = 0;
     void*  stage_csi = nullptr;     size_t stage_csi_bytes = 0;
     void*  stage_stats = nullptr;   size_t stage_stats_bytes = 0;
+    void*  stage_hbits = nullptr;   size_t stage_hbits_bytes = 0;
     void*  stage_off = nullptr;     size_t stage_off_bytes = 0;      // slot offsets of wifirx_demod_batch_v
 
     // decode workspace
     void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;
     void*  dec_max = nullptr;       size_t dec_max_bytes = 0;
-    void*  dec_masks = nullptr;     size_t dec_masks_bytes = 0;   // decode_mac: gathered coded-bit masks of a batch
+    void*  dec_hbits = nullptr;     size_t dec_hbits_bytes = 0;   // decode_mac over `idx` alone: its bit planes (wifirx_out.hbits form)
     void*  s_pack = nullptr;        size_t s_pack_bytes = 0;      // stream outputs, rows cut to their filled width
     void*  s_host = nullptr;        size_t s_host_bytes = 0;      // pinned landing zone of the packed outputs
 
@@ -79,6 +80,7 @@ struct wifirx_handle {
     void*  s_car = nullptr;   void* s_psdu = nullptr;    uint32_t s_cap = 0;
     void*  s_csi = nullptr;
     void*  s_stats = nullptr;
+    void*  s_hbits = nullptr;
     int    test_fail_alloc = 0, test_alloc_count = 0;      // WIFIRX_TEST_FAIL_ALLOC (allocation-failure tests)
 
     // Host-buffer stream path (what a GNU Radio work() drives; wifirx_api_stream.inc): pushes are copied into one of two
@@ -199,12 +201,12 @@ int wifirx_destroy(wifirx_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (float2* r : h->ring) if (r) (void)hipHostFree(r);
-    void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi, h->stage_stats, h->stage_off, h->s_stats,
+    void* bufs[] = { h->stage_iq, h->stage_frames, h->stage_idx, h->stage_llr, h->stage_car, h->stage_psdu, h->stage_csi, h->stage_stats, h->stage_hbits, h->stage_off, h->s_stats,
                      h->dec_scratch, h->dec_max, h->sbuf, h->s_above, h->s_A, h->s_trig, h->s_frames, h->s_idx,
-                     h->s_car, h->s_psdu, h->s_csi };
+                     h->s_car, h->s_psdu, h->s_csi, h->s_hbits };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->s_pack) (void)hipFree(h->s_pack);
-    if (h->dec_masks) (void)hipFree(h->dec_masks);
+    if (h->dec_hbits) (void)hipFree(h->dec_hbits);
     if (h->s_host) (void)hipHostFree(h->s_host);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -316,6 +318,7 @@ static int check_batch(wifirx_handle* h, uint32_t slot_len, uint32_t n_slots, co
     if (h->cfg.max_batch && n_slots > h->cfg.max_batch) return fail(h, WIFIRX_ERANGE, "n_slots exceeds max_batch");
     if (h->cfg.max_slot_len && slot_len > h->cfg.max_slot_len) return fail(h, WIFIRX_ERANGE, "slot_len exceeds max_slot_len");
     if (out->llr && h->cfg.llr_bits == 0) return fail(h, WIFIRX_EINVAL, "llr requested but llr_bits == 0");
+    if (out->on_device && (reinterpret_cast<uintptr_t>(out->hbits) & 15)) return fail(h, WIFIRX_EINVAL, "out->hbits must be 16-byte aligned");
     return WIFIRX_OK;
 }
 
@@ -372,6 +375,7 @@ static int demod_batch_impl(wifirx_handle* h, const float* iq, int iq_on_device,
     float2*  d_car = reinterpret_cast<float2*>(out->carrier);
     float2*  d_csi = reinterpret_cast<float2*>(out->csi);
     float4*  d_stats = reinterpret_cast<float4*>(out->sym_stats);
+    uint32_t* d_hb = out->hbits;
     if (!out->on_device) {
         if ((rc = ensure(h, &h->stage_frames, &h->stage_frames_bytes, n_slots * sizeof(wifirx_frame)))) return rc;
         d_fr = reinterpret_cast<wifirx_frame*>(h->stage_frames);
@@ -399,8 +403,13 @@ static int demod_batch_impl(wifirx_handle* h, const float* iq, int iq_on_device,
             if ((rc = ensure(h, &h->stage_stats, &h->stage_stats_bytes, (size_t)n_slots * sizeof(float4)))) return rc;
             d_stats = reinterpret_cast<float4*>(h->stage_stats);
         }
+        if (out->hbits) {
+            if ((rc = ensure(h, &h->stage_hbits, &h->stage_hbits_bytes, idx_n))) return rc;
+            d_hb = reinterpret_cast<uint32_t*>(h->stage_hbits);
+            HIP_TRY(h, hipMemsetAsync(d_hb, 0, idx_n, h->stream));
+        }
     }
-    const wr::DemodOut dout = { d_fr, d_idx, d_llr, d_car, d_csi, d_stats };
+    const wr::DemodOut dout = { d_fr, d_idx, d_llr, d_car, d_csi, d_stats, d_hb };
     HIP_TRY(h, wr_launch_demod_batch(h->stream, d_iq, slot_len, n_slots, &prm, &dout, d_off));
     h->stats.samples_in += n_iq;
     if (!out->on_device) {
@@ -410,6 +419,7 @@ static int demod_batch_impl(wifirx_handle* h, const float* iq, int iq_on_device,
         if (out->carrier) HIP_TRY(h, hipMemcpyAsync(out->carrier, d_car, idx_n * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
         if (out->csi) HIP_TRY(h, hipMemcpyAsync(out->csi, d_csi, (size_t)n_slots * 52 * sizeof(float2), hipMemcpyDeviceToHost, h->stream));
         if (out->sym_stats) HIP_TRY(h, hipMemcpyAsync(out->sym_stats, d_stats, (size_t)n_slots * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+        if (out->hbits) HIP_TRY(h, hipMemcpyAsync(out->hbits, d_hb, idx_n, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         for (uint32_t i = 0; i < n_slots; i++) {
             uint32_t f = out->frames[i].flags;
@@ -439,7 +449,7 @@ int wifirx_time_demod(wifirx_handle* h, const float* iq_dev, uint32_t slot_len, 
     for (int i = 0; i < iters; i++) {
         HIP_TRY(h, hipEventRecord(ev.e0, h->stream));
         const wr::DemodOut dout = { out->frames, out->idx, out->llr, reinterpret_cast<float2*>(out->carrier),
-                                    reinterpret_cast<float2*>(out->csi), reinterpret_cast<float4*>(out->sym_stats) };
+                                    reinterpret_cast<float2*>(out->csi), reinterpret_cast<float4*>(out->sym_stats), out->hbits };
         HIP_TRY(h, wr_launch_demod_batch(h->stream, reinterpret_cast<const float2*>(iq_dev), slot_len, n_slots, &prm, &dout, nullptr));
         HIP_TRY(h, hipEventRecord(ev.e1, h->stream));
         HIP_TRY(h, hipEventSynchronize(ev.e1));

@@ -15,9 +15,11 @@
 // stay far below 2^15 and the signed difference orders them; decisions depend on differences only.
 // Traceback, descrambling and the CRC run per lane, for its two frames.
 //
-// The received coded bits are gathered beforehand by decode_gather_kernel (one wave per frame, lane <-> trellis
-// step: de-puncture + de-interleave + bit extraction from the hard decisions) into per-frame bit masks in global
-// memory, which reach the lane that owns the frame through LDS, one 60-step chunk at a time.
+// The received coded bits come as the bit planes of the hard decisions (wifirx_out.hbits: written by the demod
+// kernels, or packed from `idx` by decode_pack_kernel): each lane copies the words of the current OFDM symbol of its
+// two frames into lane-private LDS slots and picks the coded bits of a trellis step from there -- where a coded bit
+// sits (de-puncturing + de-interleaving) is a per-rate table of one OFDM symbol, read through the scalar unit when all
+// frames of the wave share a rate.
 //
 // Results are bit-identical to the oracle's viterbi_decode(): same metrics (Hamming, erasures free),
 // same tie rule (the survivor with older bit 0 wins), same final state rule (smallest metric, lowest
@@ -33,69 +35,76 @@ namespace wr {
 #ifndef WR_DEC_WAVES_PER_SIMD
 #define WR_DEC_WAVES_PER_SIMD 4
 #endif
-#define WR_DEC_CHUNK      60                   // trellis steps per gathered mask word (10 groups of 6)
-#define WR_DEC_LDS_WORDS  (4 * WR_DECODE_FRAMES_PER_WAVE)   // per wave, 8-byte words: [A1,AV,B1,BV][frame] of the current chunk
+#define WR_DEC_CHUNK      60                   // decode_small_kernel: trellis steps per pass (lane <-> step)
+#define WR_DEC_NORM_STEPS 120                  // decode_kernel: the common minimum leaves the metrics every so many steps
 
-// Where the coded bit at position `ci` of the de-punctured stream of ONE OFDM symbol comes from: carrier (bits 0..5)
-// and bit of its decision (bits 6..8), or WR_SRC_PUNCT when the transmitter dropped it.  Every symbol carries
-// 2 * n_dbps de-punctured positions and exactly n_cbps transmitted bits, so the map repeats from symbol to symbol.
-// Rate parameters are template constants: every division below is by a compile-time constant.
+// Where the coded bit at position `ci` of the de-punctured stream of ONE OFDM symbol comes from, in the bit-plane
+// form of the decisions (wifirx_out.hbits: word 2 b + h of a symbol = bit b of bins 32 h .. 32 h + 31): bits 0..4 the
+// bit of the word (= bin & 31), bits 5..8 the word, or WR_SRC_PUNCT when the transmitter dropped the coded bit.
+// Read as 16-bit planes (plane p = 4 b + (bin >> 4), bit bin & 15) the same entry is p = bits 4..8, bit = bits 0..3.
+// Every symbol carries 2 * n_dbps de-punctured positions and exactly n_cbps transmitted bits, so the map repeats from
+// symbol to symbol.
 #define WR_SRC_PUNCT 0x200u
-template <int PUNCT, int N_BPSC>
-__device__ __forceinline__ uint32_t coded_src(int ci)
+#define WR_DEC_TAB_STRIDE 216              // steps per OFDM symbol at the highest rate
+constexpr int bin_of_carrier(int c)         // data carrier 0..47 -> FFT bin, shifted order (bin 32 = DC)
 {
-    constexpr int n_cbps = 48 * N_BPSC;
-    constexpr int s = (N_BPSC / 2) < 1 ? 1 : (N_BPSC / 2);
-    int pidx;
-    if (PUNCT == 0) {
-        pidx = ci;
-    } else if (PUNCT == 1) {               // 2/3: every 4th bit dropped
-        int r = ci & 3;
+    int i = c + 6;
+    if (i >= 11) i++;
+    if (i >= 25) i++;
+    if (i >= 32) i++;
+    if (i >= 39) i++;
+    if (i >= 53) i++;
+    return i;
+}
+constexpr uint32_t coded_src(int punct, int n_bpsc, int ci)
+{
+    const int n_cbps = 48 * n_bpsc;
+    const int s = (n_bpsc / 2) < 1 ? 1 : (n_bpsc / 2);
+    int pidx = ci;
+    if (punct == 1) {                      // 2/3: every 4th bit dropped
+        const int r = ci & 3;
         if (r == 3) return WR_SRC_PUNCT;
         pidx = (ci >> 2) * 3 + r;
-    } else {                               // 3/4: bits 3,4 of every 6 dropped
-        int g = ci / 6, r = ci - 6 * g;
+    } else if (punct == 2) {               // 3/4: bits 3,4 of every 6 dropped
+        const int g = ci / 6, r = ci - 6 * g;
         if (r == 3 || r == 4) return WR_SRC_PUNCT;
         pidx = g * 4 + (r < 3 ? r : 3);
     }
     const int k = pidx;                    // < n_cbps: first symbol
-    int i = (n_cbps >> 4) * (k & 15) + (k >> 4);
-    int j = s * (i / s) + (i + n_cbps - (16 * i) / n_cbps) % s;
-    int carrier = j / N_BPSC, bit = j - carrier * N_BPSC;
-    return (uint32_t)carrier | ((uint32_t)bit << 6);
+    const int i = (n_cbps >> 4) * (k & 15) + (k >> 4);
+    const int j = s * (i / s) + (i + n_cbps - (16 * i) / n_cbps) % s;
+    const int carrier = j / n_bpsc, bit = j - carrier * n_bpsc;
+    const int bin = bin_of_carrier(carrier);
+    return (uint32_t)(bin & 31) | ((uint32_t)(2 * bit + (bin >> 5)) << 5);
 }
-
-__device__ __forceinline__ uint32_t coded_src_of(int enc, int ci)
-{
-    switch (enc) {
-    case 0:  return coded_src<0, 1>(ci);
-    case 1:  return coded_src<2, 1>(ci);
-    case 2:  return coded_src<0, 2>(ci);
-    case 3:  return coded_src<2, 2>(ci);
-    case 4:  return coded_src<0, 4>(ci);
-    case 5:  return coded_src<2, 4>(ci);
-    case 6:  return coded_src<1, 6>(ci);
-    default: return coded_src<2, 6>(ci);
-    }
-}
-
-#define WR_DEC_TAB_STRIDE 216              // steps per OFDM symbol at the highest rate
-// the workgroup's source table: entry [enc][tt] = source of coded bit A (low half) and B (high half) of step tt
-__device__ __forceinline__ void build_src_table(uint32_t* tab)
+struct SrcTable { uint32_t e[8 * WR_DEC_TAB_STRIDE]; };    // [enc][step of the symbol]: coded bit A in the low half, B in the high half
+constexpr SrcTable make_src_table()
 {
     const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
-    for (int e = threadIdx.x; e < 8 * WR_DEC_TAB_STRIDE; e += blockDim.x) {
-        const int enc = e / WR_DEC_TAB_STRIDE, tt = e - enc * WR_DEC_TAB_STRIDE;
-        uint32_t v = WR_SRC_PUNCT | (WR_SRC_PUNCT << 16);
-        if (tt < ndbps_tab[enc]) v = coded_src_of(enc, 2 * tt) | (coded_src_of(enc, 2 * tt + 1) << 16);
-        tab[e] = v;
-    }
+    const int punct_tab[8] = { 0, 2, 0, 2, 0, 2, 1, 2 };
+    const int nbpsc_tab[8] = { 1, 1, 2, 2, 4, 4, 6, 6 };
+    SrcTable t{};
+    for (int enc = 0; enc < 8; enc++)
+        for (int tt = 0; tt < WR_DEC_TAB_STRIDE; tt++) {
+            uint32_t v = WR_SRC_PUNCT | (WR_SRC_PUNCT << 16);
+            if (tt < ndbps_tab[enc])
+                v = coded_src(punct_tab[enc], nbpsc_tab[enc], 2 * tt) | (coded_src(punct_tab[enc], nbpsc_tab[enc], 2 * tt + 1) << 16);
+            t.e[enc * WR_DEC_TAB_STRIDE + tt] = v;
+        }
+    return t;
+}
+__constant__ const SrcTable WR_SRC_TABLE = make_src_table();
+
+// the workgroup's copy in LDS (lane-dependent look-ups)
+__device__ __forceinline__ void copy_src_table(uint32_t* tab)
+{
+    for (int e = threadIdx.x; e < 8 * WR_DEC_TAB_STRIDE; e += blockDim.x) tab[e] = WR_SRC_TABLE.e[e];
 }
 
 // The received value (0, 1, or 2 = punctured / beyond the tile) of the coded bits A and B of step t of one frame.
-// `tile` holds the decisions of the symbols sym0.. of the frame (48 bytes each, LDS); n_dbps and its reciprocal
+// `tile` holds the bit-plane words of the symbols sym0.. of the frame (n_words each, LDS); n_dbps and its reciprocal
 // (ceil(2^32 / n_dbps): exact quotients for every t < 2^17) are wave-uniform.
-__device__ __forceinline__ void gather_step(const uint8_t* tile, int sym0, const uint32_t* __restrict__ tab_enc,
+__device__ __forceinline__ void gather_step(const uint32_t* tile, int sym0, int n_words, const uint32_t* __restrict__ tab_enc,
                                             int n_dbps, uint32_t recip, int t, bool in_range, int& ra, int& rb)
 {
     ra = 2; rb = 2;
@@ -104,9 +113,9 @@ __device__ __forceinline__ void gather_step(const uint8_t* tile, int sym0, const
         const int tt = t - sym * n_dbps;
         const uint32_t e = tab_enc[tt];
         const uint32_t ea = e & 0xffffu, eb = e >> 16;
-        const uint8_t* sp = tile + (sym - sym0) * 48;
-        if (!(ea & WR_SRC_PUNCT)) ra = (sp[ea & 63u] >> (ea >> 6)) & 1;
-        if (!(eb & WR_SRC_PUNCT)) rb = (sp[eb & 63u] >> (eb >> 6)) & 1;
+        const uint32_t* sp = tile + (sym - sym0) * n_words;
+        if (!(ea & WR_SRC_PUNCT)) ra = (int)((sp[(ea >> 5) & 15u] >> (ea & 31u)) & 1u);
+        if (!(eb & WR_SRC_PUNCT)) rb = (int)((sp[(eb >> 5) & 15u] >> (eb & 31u)) & 1u);
     }
 }
 
@@ -124,64 +133,61 @@ __device__ __forceinline__ int frame_steps(uint32_t flags, int enc, int len, uin
 
 #define WR_RECIP32(d) (uint32_t)((0x100000000ull + (d) - 1) / (d))      /* ceil(2^32 / d) */
 
-// ---- gather kernel: the received coded bits of every frame as 60-step bit masks, one wave per frame with lane <->
-//      trellis step.  The decisions of a frame come in tiles of 60 OFDM symbols (a whole number of chunks at every
-//      rate), copied into the wave's LDS by coalesced 16-byte loads.  Output layout: for decode task T (the
-//      frames_per_wave frames one wave of decode_kernel handles) [chunk][A1,AV,B1,BV][frame position 0..127]. ----
-__global__ __launch_bounds__(256)
-void decode_gather_kernel(uint32_t n_slots, uint32_t max_sym, const wifirx_frame* __restrict__ frames,
-                          const uint8_t* __restrict__ idx_all, uint32_t psdu_stride, uint64_t* __restrict__ masks_all,
-                          uint32_t n_steps_cap, uint32_t frames_per_wave)
+// ---- pack kernel: `idx` (one byte per data carrier) -> bit planes (wifirx_out.hbits), for callers that hand
+//      wifirx_decode_batch decisions without planes.  One wave per frame, lane <-> OFDM symbol: 48 bytes in, 2 n_bpsc
+//      words out, both contiguous over the lanes. ----
+template <int NB>
+__device__ __forceinline__ void pack_symbol(const uint32_t (&by)[12], uint32_t* __restrict__ dst)
 {
-    __shared__ uint8_t tile_all[4][60 * 48];
-    __shared__ uint32_t src_tab[8 * WR_DEC_TAB_STRIDE];
-    build_src_table(src_tab);
-    __syncthreads();
+    uint32_t w[2 * NB];
+#pragma unroll
+    for (int k = 0; k < 2 * NB; k++) w[k] = 0;
+#pragma unroll
+    for (int c = 0; c < 48; c++) {
+        const int bin = bin_of_carrier(c);
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+            w[2 * b + (bin >> 5)] |= ((by[c >> 2] >> (8 * (c & 3) + b)) & 1u) << (bin & 31);
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * NB; k++) dst[k] = w[k];
+}
+
+__global__ __launch_bounds__(256)
+void decode_pack_kernel(uint32_t n_slots, uint32_t max_sym, const wifirx_frame* __restrict__ frames,
+                        const uint8_t* __restrict__ idx_all, uint32_t psdu_stride, uint32_t* __restrict__ hbits_all,
+                        uint32_t n_steps_cap)
+{
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    uint8_t* tile = tile_all[wv];
     const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
-    const uint32_t recip_tab[8] = { WR_RECIP32(24), WR_RECIP32(36), WR_RECIP32(48), WR_RECIP32(72),
-                                    WR_RECIP32(96), WR_RECIP32(144), WR_RECIP32(192), WR_RECIP32(216) };
-    const bool idx16 = ((reinterpret_cast<uintptr_t>(idx_all) | ((size_t)max_sym * 48)) & 15) == 0;
-    const uint32_t fA = frames_per_wave < 64 ? frames_per_wave : 64;
-    const size_t task_words = ((size_t)n_steps_cap / WR_DEC_CHUNK + 2) * 4 * WR_DECODE_FRAMES_PER_WAVE;
+    const bool idx4 = ((reinterpret_cast<uintptr_t>(idx_all) | ((size_t)max_sym * 48)) & 3) == 0;
     for (uint32_t slot = blockIdx.x * 4 + wv; slot < n_slots; slot += gridDim.x * 4) {
         const wifirx_frame fr = frames[slot];
-        const int f_enc = fr.encoding & 7;
-        const int f_ndata = frame_steps(fr.flags, f_enc, fr.psdu_len, psdu_stride, max_sym, n_steps_cap);
-        if (f_ndata == 0) continue;
-        const uint32_t task = slot / frames_per_wave, rr = slot - task * frames_per_wave;
-        const uint32_t f = rr < fA ? rr : 64 + (rr - fA);           // position in the decode wave: lane f & 63, half f >> 6
-        uint64_t* masks = masks_all + (size_t)task * task_words;
+        const int enc = fr.encoding & 7;
+        const int n_data = frame_steps(fr.flags, enc, fr.psdu_len, psdu_stride, max_sym, n_steps_cap);
+        if (n_data == 0) continue;                                    // wave-uniform: one frame per wave
+        const int n_sym = n_data / ndbps_tab[enc];
+        const int nb = enc < 2 ? 1 : enc < 4 ? 2 : enc < 6 ? 4 : 6;
         const uint8_t* fidx = idx_all + (size_t)slot * max_sym * 48;
-        const int f_ndbps = ndbps_tab[f_enc];
-        const uint32_t f_recip = recip_tab[f_enc];
-        const int f_nsym = f_ndata / f_ndbps;
-        for (int sym0 = 0; sym0 < f_nsym; sym0 += 60) {
-            const int nsy = f_nsym - sym0 < 60 ? f_nsym - sym0 : 60;
-            const int nbytes = nsy * 48;
-            __builtin_amdgcn_wave_barrier();
-            if (idx16) {
-                for (int o = lane * 16; o < nbytes; o += 1024)
-                    *reinterpret_cast<uint4*>(tile + o) = *reinterpret_cast<const uint4*>(fidx + sym0 * 48 + o);
+        uint32_t* fhb = hbits_all + (size_t)slot * max_sym * 12;
+        for (int q = lane; q < n_sym; q += 64) {
+            uint32_t by[12];
+            if (idx4) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) by[k] = reinterpret_cast<const uint32_t*>(fidx + (size_t)q * 48)[k];
             } else {
-                for (int o = lane; o < nbytes; o += 64) tile[o] = fidx[sym0 * 48 + o];
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int t_hi = (sym0 + nsy) * f_ndbps;
-            for (int c = sym0 * f_ndbps / WR_DEC_CHUNK; c * WR_DEC_CHUNK < t_hi; c++) {
-                const int t = c * WR_DEC_CHUNK + lane;
-                int ra, rb;
-                gather_step(tile, sym0, src_tab + f_enc * WR_DEC_TAB_STRIDE, f_ndbps, f_recip, t,
-                            lane < WR_DEC_CHUNK && t < t_hi, ra, rb);
-                const uint64_t A1 = __ballot(ra == 1), AV = __ballot(ra != 2);
-                const uint64_t B1 = __ballot(rb == 1), BV = __ballot(rb != 2);
-                if (lane < 4) {
-                    uint64_t wsel = lane == 0 ? A1 : lane == 1 ? AV : lane == 2 ? B1 : BV;
-                    masks[((size_t)c * 4 + lane) * WR_DECODE_FRAMES_PER_WAVE + f] = wsel;
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const uint8_t* p = fidx + (size_t)q * 48 + 4 * k;
+                    by[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
                 }
             }
+            uint32_t* dst = fhb + (size_t)q * 2 * nb;
+            if (nb == 1)      pack_symbol<1>(by, dst);
+            else if (nb == 2) pack_symbol<2>(by, dst);
+            else if (nb == 4) pack_symbol<4>(by, dst);
+            else              pack_symbol<6>(by, dst);
         }
     }
 }
@@ -319,43 +325,73 @@ __device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, in
     rec->flags = fl;
 }
 
+// Six lane-private LDS reads whose rows come from the scalar unit: word[lane] of the rows at byte addresses a[0..5]
+// (ds_read_addtid_b32: LDS[M0 + 4 * lane], tools/lds_addtid_probe.hip) -- no address register, no add per read, all six in
+// flight together.  One wait state between the write of M0 and the LDS instruction that reads it.
+__device__ __forceinline__ void lds_rows6(const uint32_t (&a)[6], uint32_t (&w)[6])
+{
+    asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\tds_read_addtid_b32 %0\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tds_read_addtid_b32 %1\n\t"
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tds_read_addtid_b32 %2\n\t"
+                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tds_read_addtid_b32 %3\n\t"
+                 "s_mov_b32 m0, %10\n\ts_nop 0\n\tds_read_addtid_b32 %4\n\t"
+                 "s_mov_b32 m0, %11\n\ts_nop 0\n\tds_read_addtid_b32 %5\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
+                 : "s"(a[0]), "s"(a[1]), "s"(a[2]), "s"(a[3]), "s"(a[4]), "s"(a[5])
+                 : "m0", "memory");
+}
+
+// MIXED = false: the tasks whose frames all share one rate (the usual case: where a coded bit sits is then the same
+// for every lane, and comes through the scalar unit).  MIXED = true: the other tasks (per-lane look-ups).  Both kernels are
+// launched over the same tasks, one after the other on the stream, and each leaves the other's tasks alone.
+template <bool MIXED>
 __global__ __launch_bounds__(256, WR_DEC_WAVES_PER_SIMD)
 void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
-                   const uint8_t* __restrict__ idx_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
+                   const uint32_t* __restrict__ hbits_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
                    uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total,
-                   uint32_t frames_per_wave, const uint64_t* __restrict__ masks_all)
+                   uint32_t frames_per_wave)
 {
-    __shared__ uint64_t lds_all[4][WR_DEC_LDS_WORDS];
+    // the current OFDM symbols of the wave's frames, lane-private columns.  One rate: row 2 w + g (w = word of the staged
+    // block, g = 0, 1) = 16-bit plane g of the word of frame A | that of frame B << 16 (plane p of a symbol = row 2 n_w s + p
+    // for the s-th symbol of the block); mixed rates: row 12 h + k = word k of the current symbol of the frame of half h.
+    __shared__ uint32_t sym_all[4][(MIXED ? 24 : 32) * 64];
+    __shared__ uint32_t src_tab[MIXED ? 8 * WR_DEC_TAB_STRIDE : 1];
     __shared__ FinishTables ft;
+    if (MIXED) copy_src_table(src_tab);
     build_finish_tables(ft);
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * 4 + wv;
     if (wave >= n_waves_total) return;
-    uint64_t* lds = lds_all[wv];
+    uint32_t* symw = sym_all[wv] + lane;
+    const uint32_t sym_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)sym_all[wv]);     // LDS byte address of the wave's rows
     const size_t n_data_cap = n_steps_cap;               // trellis steps the scratch slice of a wave holds
     uint32_t* surv = reinterpret_cast<uint32_t*>(scratch + (size_t)wave * scratch_stride);   // [step][lane][4 pieces]
     uint32_t* dbits = surv + n_data_cap * 256;                                               // [word][A/B][lane]
     const uint32_t k1 = 0x00010001u;
+    const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
+    const uint32_t hb_stride = max_sym * 12;             // words per frame
 
     // A wave's tasks (frames_per_wave <= 128 frames each, grid-stride); lane l owns frames base + l (l < fA) and
-    // base + fA + l (l < fB).  The coded-bit masks of every task were written by decode_gather_kernel.
+    // base + fA + l (l < fB).
     const uint32_t fA = frames_per_wave < 64 ? frames_per_wave : 64, fB = frames_per_wave - fA;
-    const size_t task_words = ((size_t)n_data_cap / WR_DEC_CHUNK + 2) * 4 * WR_DECODE_FRAMES_PER_WAVE;
     const uint32_t n_tasks = (n_slots + frames_per_wave - 1) / frames_per_wave;
     for (uint32_t task = wave; task < n_tasks; task += n_waves_total) {
         const uint32_t base = task * frames_per_wave;
-        const uint64_t* masks = masks_all + (size_t)task * task_words;
+        const uint32_t* hb_task = hbits_all + (size_t)base * hb_stride;
         // ---- my two frames ----
-        int n_data[2];
+        int n_data[2], enc[2];
         int n_max = 0;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t slot = base + (h ? fA : 0u) + lane;
             n_data[h] = 0;
-            if ((uint32_t)lane < (h ? fB : fA) && slot < n_slots)
-                n_data[h] = frame_steps(frames[slot].flags, frames[slot].encoding, frames[slot].psdu_len, psdu_stride, max_sym,
-                                        n_steps_cap);
+            enc[h] = 0;
+            if ((uint32_t)lane < (h ? fB : fA) && slot < n_slots) {
+                enc[h] = frames[slot].encoding & 7;
+                n_data[h] = frame_steps(frames[slot].flags, enc[h], frames[slot].psdu_len, psdu_stride, max_sym, n_steps_cap);
+            }
             n_max = n_data[h] > n_max ? n_data[h] : n_max;
         }
 #pragma unroll
@@ -363,80 +399,167 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
             int o = __shfl_xor(n_max, k, 64);
             n_max = o > n_max ? o : n_max;
         }
+        n_max = __builtin_amdgcn_readfirstlane(n_max);
         if (n_max == 0) continue;
+        // one rate for all frames of the task?
+        const uint64_t actA = __ballot(n_data[0] > 0), actB = __ballot(n_data[1] > 0);
+        const int enc_u = actA ? __builtin_amdgcn_readlane(enc[0], (int)__builtin_ctzll(actA))
+                               : __builtin_amdgcn_readlane(enc[1], (int)__builtin_ctzll(actB));
+        const bool uni_rate = __all((n_data[0] == 0 || enc[0] == enc_u) && (n_data[1] == 0 || enc[1] == enc_u));
+        if (uni_rate == MIXED) continue;                 // the other kernel's task
+        const int nd_u = ndbps_tab[enc_u];
+        const int nw_u = enc_u < 2 ? 2 : enc_u < 4 ? 4 : enc_u < 6 ? 8 : 12;        // words per symbol
+        const int sym_blk = enc_u < 2 ? 8 : enc_u < 4 ? 4 : enc_u < 6 ? 2 : 1;      // symbols staged together (one rate)
+        const int n_ld = enc_u < 6 ? 16 : 12;                                       // = sym_blk * nw_u words
+        const uint32_t offA = (uint32_t)lane * hb_stride, offB = (fA + (uint32_t)lane) * hb_stride;
 
         // ---- phase 2: add-compare-select ----
         uint32_t pm[64];
 #pragma unroll
         for (int s = 0; s < 64; s++) pm[s] = (s == 0) ? 0u : WR_DEC_START_PENALTY;
         int best[2] = { 0, 0 };                         // final states, taken when the frames end
-        for (int t0 = 0, c = 0; t0 < n_max; t0 += WR_DEC_CHUNK, c++) {
-            // my two frames' mask words of this chunk: global -> LDS (lane-private slots), re-read six steps at a time
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                lds[w * WR_DECODE_FRAMES_PER_WAVE + lane] = masks[((size_t)c * 4 + w) * WR_DECODE_FRAMES_PER_WAVE + lane];
-                lds[w * WR_DECODE_FRAMES_PER_WAVE + 64 + lane] = masks[((size_t)c * 4 + w) * WR_DECODE_FRAMES_PER_WAVE + 64 + lane];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if ((c & 1) == 0 && c > 0) {
-                // every 120 steps: subtract the common minimum of each frame (register phase 0 here; decisions see
-                // differences only)
+        int tt_u = 0, sym_u = 0, since_norm = 0;        // wave-uniform: step within the symbol, symbol (one rate), steps since the minimum left
+        uint32_t pos[2] = { 0u, 0u };                   // mixed rates, per lane and half: symbol << 8 | step within the symbol
+        for (int tg = 0; tg < n_max; tg += 6) {
+            if (since_norm == WR_DEC_NORM_STEPS) {
+                // subtract the common minimum of each frame (register phase 0 here; decisions see differences only)
+                since_norm = 0;
                 uint32_t mn = pm[0];
 #pragma unroll
                 for (int s = 1; s < 64; s++) mn = pk_min(mn, pm[s]);
 #pragma unroll
                 for (int s = 0; s < 64; s++) pm[s] = pk_sub(pm[s], mn);
             }
-            {
-                for (int g = 0; g < WR_DEC_CHUNK / 6; g++) {
-                    const int tg = t0 + 6 * g;
-                    if (tg >= n_max) break;
-                    // six steps of the four mask words, frame A in bits 0..5, frame B in bits 16..21 (re-read from LDS
-                    // every group: registers are what this kernel is short of)
-                    uint32_t pw[4];
+            since_norm += 6;
+            // ---- a new OFDM symbol: its bit-plane words, global -> lane-private LDS ----
+            if (!MIXED) {
+                // 16 words (64 bytes: a whole memory segment) per frame at a time = 8 / 4 / 2 symbols at 1 / 2 / 4 bits per
+                // carrier; 12 words = one symbol at 6
+                if (tt_u == nd_u) { tt_u = 0; sym_u++; }
+                if (tt_u == 0 && (sym_u & (sym_blk - 1)) == 0) {
+                    const bool okA = tg < n_data[0], okB = tg < n_data[1];
+#ifdef WR_DEC_EXP_COMPACT       /* experiment: all staging loads from one small, always cached region (results are garbage) */
+                    const uint32_t* pa = hbits_all + lane * 16 + (sym_u & 7) * 2048;
+                    const uint32_t* pb = pa + 1024;
+#else
+                    const uint32_t* pa = hb_task + offA + (uint32_t)(sym_u * nw_u);
+                    const uint32_t* pb = hb_task + offB + (uint32_t)(sym_u * nw_u);
+#endif
+                    const uint32_t room = hb_stride - (uint32_t)(sym_u * nw_u);      // words left in a frame's row
 #pragma unroll
-                    for (int w = 0; w < 4; w++) {
-                        const uint64_t wa = lds[w * WR_DECODE_FRAMES_PER_WAVE + lane];
-                        const uint64_t wb = lds[w * WR_DECODE_FRAMES_PER_WAVE + 64 + lane];
-                        pw[w] = ((uint32_t)(wa >> (6 * g)) & 0x3fu) | (((uint32_t)(wb >> (6 * g)) & 0x3fu) << 16);
-                    }
-                    const bool mine0 = tg < n_data[0], mine1 = tg < n_data[1];
-                    if (mine0 || mine1) {
-#define WR_ACS(P)                                                                                         \
-                        {                                                                                 \
-                            const uint32_t ta = (pw[0] >> P) & k1, va = (pw[1] >> P) & k1;                \
-                            const uint32_t tb = (pw[2] >> P) & k1, vb = (pw[3] >> P) & k1;                \
-                            const uint32_t nv = va + vb;          /* a set bit implies its valid bit */   \
-                            uint32_t M[2][2];                                                             \
-                            M[0][0] = ta + tb;                                                            \
-                            M[0][1] = ta + vb - tb;                                                       \
-                            M[1][1] = nv - M[0][0];                                                       \
-                            M[1][0] = nv - M[0][1];                                                       \
-                            uint32_t acc[4];                                                              \
-                            acs_step<P>(pm, M, acc);                                             \
-                            *reinterpret_cast<uint4*>(surv + ((size_t)(tg + P) * 64 + lane) * 4) =        \
-                                make_uint4(acc[0], acc[1], acc[2], acc[3]);                               \
+                    for (int k = 0; k < 16; k += 4) {
+                        if (k < n_ld) {
+                            uint4 a = make_uint4(0u, 0u, 0u, 0u), b = make_uint4(0u, 0u, 0u, 0u);
+                            if (okA && (uint32_t)k + 4 <= room) a = *reinterpret_cast<const uint4*>(pa + k);
+                            if (okB && (uint32_t)k + 4 <= room) b = *reinterpret_cast<const uint4*>(pb + k);
+                            uint32_t* d = symw + 2 * k * 64;
+                            d[0 * 64] = (a.x & 0xffffu) | (b.x << 16);  d[1 * 64] = (a.x >> 16) | (b.x & 0xffff0000u);
+                            d[2 * 64] = (a.y & 0xffffu) | (b.y << 16);  d[3 * 64] = (a.y >> 16) | (b.y & 0xffff0000u);
+                            d[4 * 64] = (a.z & 0xffffu) | (b.z << 16);  d[5 * 64] = (a.z >> 16) | (b.z & 0xffff0000u);
+                            d[6 * 64] = (a.w & 0xffffu) | (b.w << 16);  d[7 * 64] = (a.w >> 16) | (b.w & 0xffff0000u);
                         }
-                        WR_ACS(0) WR_ACS(1) WR_ACS(2) WR_ACS(3) WR_ACS(4) WR_ACS(5)
-#undef WR_ACS
                     }
-                    const bool end0 = mine0 && tg + 6 == n_data[0], end1 = mine1 && tg + 6 == n_data[1];
-                    if (__any(end0 || end1)) {
-                        // a frame just ended (register phase 0 again): smallest metric, lowest state
-                        uint32_t bm0 = pm[0] & 0xffffu, bm1 = pm[0] >> 16;
-                        int bs0 = 0, bs1 = 0;
+                }
+            } else {
 #pragma unroll
-                        for (int s = 1; s < 64; s++) {
-                            const uint32_t v0 = pm[s] & 0xffffu, v1 = pm[s] >> 16;
-                            if (v0 < bm0) { bm0 = v0; bs0 = s; }
-                            if (v1 < bm1) { bm1 = v1; bs1 = s; }
-                        }
-                        if (end0) best[0] = bs0;
-                        if (end1) best[1] = bs1;
+                for (int h = 0; h < 2; h++) {
+                    const int nd = ndbps_tab[enc[h]];
+                    if ((int)(pos[h] & 0xffu) == nd) pos[h] = (pos[h] & ~0xffu) + 0x100u;
+                    if ((pos[h] & 0xffu) == 0u && tg < n_data[h]) {
+                        const int nw = enc[h] < 2 ? 2 : enc[h] < 4 ? 4 : enc[h] < 6 ? 8 : 12;
+                        const uint32_t* ps = hb_task + (h ? offB : offA) + (pos[h] >> 8) * (uint32_t)nw;
+                        for (int k = 0; k < nw; k++) symw[(12 * h + k) * 64] = ps[k];
                     }
                 }
             }
+            const bool mine0 = tg < n_data[0], mine1 = tg < n_data[1];
+            // one trellis step: the coded bits A, B of both frames (ta, tb: frame A in bit 0, frame B in bit 16) and
+            // whether they were transmitted (va, vb)
+#define WR_ACS(P, ta, tb, va, vb)                                                                         \
+                    {                                                                                     \
+                        const uint32_t nv = (va) + (vb);      /* a set bit implies its valid bit */       \
+                        uint32_t M[2][2];                                                                 \
+                        M[0][0] = (ta) + (tb);                                                            \
+                        M[0][1] = (ta) + (vb) - (tb);                                                     \
+                        M[1][1] = nv - M[0][0];                                                           \
+                        M[1][0] = nv - M[0][1];                                                           \
+                        uint32_t acc[4];                                                                  \
+                        acs_step<P>(pm, M, acc);                                                          \
+                        *reinterpret_cast<uint4*>(surv + ((size_t)(tg + P) * 64 + lane) * 4) =            \
+                            make_uint4(acc[0], acc[1], acc[2], acc[3]);                                   \
+                    }
+            if (!MIXED) {
+                // Three steps at a time: their six rows (A and B of each step) are read together, rows and bit positions
+                // from the scalar unit; a punctured position reads plane 0 and is masked away (no branches).
+                const uint32_t* te = WR_SRC_TABLE.e + (enc_u * WR_DEC_TAB_STRIDE + tt_u);      // wave-uniform: scalar loads
+                const uint32_t blk_lds = sym_lds + (uint32_t)((sym_u & (sym_blk - 1)) * nw_u) * 512u;      // this symbol's rows
+                uint32_t e[6];
+#pragma unroll
+                for (int P = 0; P < 6; P++) e[P] = te[P];
+#define WR_FETCH3(Q)                                                                                      \
+                uint32_t rr##Q[6], ww##Q[6];                                                              \
+                _Pragma("unroll") for (int k = 0; k < 3; k++) {                                           \
+                    rr##Q[k] = blk_lds + ((e[Q + k] << 4) & 0x1f00u);      /* plane p = bits 4..8 of the half: row p, 256 bytes each */ \
+                    rr##Q[3 + k] = blk_lds + ((e[Q + k] >> 12) & 0x1f00u);                                \
+                }                                                                                         \
+                lds_rows6(rr##Q, ww##Q);
+#define WR_ACS_U(P, Q)                                                                                    \
+                {                                                                                         \
+                    const uint32_t ea = e[P] & 0xffffu, eb = e[P] >> 16;                                  \
+                    const uint32_t va = k1 & (((ea >> 9) & 1u) - 1u), vb = k1 & (((eb >> 9) & 1u) - 1u);  \
+                    const uint32_t ta = (ww##Q[P - Q] >> (ea & 15u)) & va, tb = (ww##Q[3 + P - Q] >> (eb & 15u)) & vb; \
+                    WR_ACS(P, ta, tb, va, vb)                                                             \
+                }
+                if (mine0 || mine1) {
+                    { WR_FETCH3(0)  WR_ACS_U(0, 0) WR_ACS_U(1, 0) WR_ACS_U(2, 0) }
+                    { WR_FETCH3(3)  WR_ACS_U(3, 3) WR_ACS_U(4, 3) WR_ACS_U(5, 3) }
+                }
+#undef WR_ACS_U
+#undef WR_FETCH3
+            } else {
+                // six steps of coded bits: pw[0] / pw[2] = bits A / B (step P of frame A in bit P, of frame B in bit 16 + P),
+                // pw[1] / pw[3] = whether they were transmitted
+                uint32_t pw[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t* te = src_tab + enc[h] * WR_DEC_TAB_STRIDE + (int)(pos[h] & 0xffu);
+                    const uint32_t* sw = symw + 12 * h * 64;
+#pragma unroll
+                    for (int P = 0; P < 6; P++) {
+                        const uint32_t e = te[P];
+                        const uint32_t ea = e & 0xffffu, eb = e >> 16;
+                        const uint32_t va = ((ea >> 9) & 1u) ^ 1u, vb = ((eb >> 9) & 1u) ^ 1u;
+                        pw[0] |= ((sw[((ea >> 5) & 15u) * 64] >> (ea & 31u)) & va) << (16 * h + P);
+                        pw[1] |= va << (16 * h + P);
+                        pw[2] |= ((sw[((eb >> 5) & 15u) * 64] >> (eb & 31u)) & vb) << (16 * h + P);
+                        pw[3] |= vb << (16 * h + P);
+                    }
+                }
+                if (mine0 || mine1) {
+#define WR_ACS_M(P) WR_ACS(P, (pw[0] >> P) & k1, (pw[2] >> P) & k1, (pw[1] >> P) & k1, (pw[3] >> P) & k1)
+                    WR_ACS_M(0) WR_ACS_M(1) WR_ACS_M(2) WR_ACS_M(3) WR_ACS_M(4) WR_ACS_M(5)
+#undef WR_ACS_M
+                }
+            }
+#undef WR_ACS
+            {
+                const bool end0 = mine0 && tg + 6 == n_data[0], end1 = mine1 && tg + 6 == n_data[1];
+                if (__any(end0 || end1)) {
+                    // a frame just ended (register phase 0 again): smallest metric, lowest state
+                    uint32_t bm0 = pm[0] & 0xffffu, bm1 = pm[0] >> 16;
+                    int bs0 = 0, bs1 = 0;
+#pragma unroll
+                    for (int s = 1; s < 64; s++) {
+                        const uint32_t v0 = pm[s] & 0xffffu, v1 = pm[s] >> 16;
+                        if (v0 < bm0) { bm0 = v0; bs0 = s; }
+                        if (v1 < bm1) { bm1 = v1; bs1 = s; }
+                    }
+                    if (end0) best[0] = bs0;
+                    if (end1) best[1] = bs1;
+                }
+            }
+            tt_u += 6;
+            if (MIXED) { pos[0] += 6u; pos[1] += 6u; }
         }
         __threadfence_block();
         // ---- traceback of both frames: 32 decoded bits per word, words stored [word][A/B][lane].  The survivor
@@ -546,18 +669,18 @@ __device__ __forceinline__ uint32_t crc32_update(uint32_t c, uint32_t byte)
 
 __global__ __launch_bounds__(256)
 void decode_small_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
-                         const uint8_t* __restrict__ idx_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
+                         const uint32_t* __restrict__ hbits_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
                          uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total)
 {
-    __shared__ uint8_t tile_all[4][60 * 48];
+    __shared__ uint32_t tile_all[4][60 * 12];
     __shared__ uint32_t src_tab[8 * WR_DEC_TAB_STRIDE];
-    build_src_table(src_tab);
+    copy_src_table(src_tab);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const uint32_t wave = blockIdx.x * 4 + wv;
     if (wave >= n_waves_total) return;
-    uint8_t* tile = tile_all[wv];
+    uint32_t* tile = tile_all[wv];
     uint64_t* dec = reinterpret_cast<uint64_t*>(scratch + (size_t)wave * scratch_stride);     // survivor word per step
     uint64_t* words = dec + n_steps_cap;                                                      // decoded bits, 60 per word
 
@@ -566,11 +689,8 @@ void decode_small_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __res
     const int f0 = (p0 << 1) | u;
     const int a0 = __builtin_popcount(f0 & 0155) & 1, b0 = __builtin_popcount(f0 & 0117) & 1;
     const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
-#define WR_RECIP32(d) (uint32_t)((0x100000000ull + (d) - 1) / (d))
     const uint32_t recip_tab[8] = { WR_RECIP32(24), WR_RECIP32(36), WR_RECIP32(48), WR_RECIP32(72),
                                     WR_RECIP32(96), WR_RECIP32(144), WR_RECIP32(192), WR_RECIP32(216) };
-#undef WR_RECIP32
-    const bool idx16 = ((reinterpret_cast<uintptr_t>(idx_all) | ((size_t)max_sym * 48)) & 15) == 0;
 
     for (uint32_t slot = wave; slot < n_slots; slot += n_waves_total) {
         const wifirx_frame fr = frames[slot];
@@ -581,7 +701,8 @@ void decode_small_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __res
                         n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym && (uint32_t)(n_sym * n_dbps) <= n_steps_cap;
         if (!ok) continue;                                       // wave-uniform: one frame per wave
         const int n_data = n_sym * n_dbps;
-        const uint8_t* fidx = idx_all + (size_t)slot * max_sym * 48;
+        const int n_words = enc < 2 ? 2 : enc < 4 ? 4 : enc < 6 ? 8 : 12;           // bit-plane words per symbol
+        const uint32_t* fhb = hbits_all + (size_t)slot * max_sym * 12;
         const uint32_t recip = recip_tab[enc];
         const uint32_t* tab_enc = src_tab + enc * WR_DEC_TAB_STRIDE;
 
@@ -589,20 +710,15 @@ void decode_small_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __res
         int pm = (s == 0) ? 0 : (1 << 24);
         for (int sym0 = 0; sym0 < n_sym; sym0 += 60) {
             const int nsy = n_sym - sym0 < 60 ? n_sym - sym0 : 60;
-            const int nbytes = nsy * 48;
+            const int nw = nsy * n_words;
             __builtin_amdgcn_wave_barrier();
-            if (idx16) {
-                for (int o = lane * 16; o < nbytes; o += 1024)
-                    *reinterpret_cast<uint4*>(tile + o) = *reinterpret_cast<const uint4*>(fidx + sym0 * 48 + o);
-            } else {
-                for (int o = lane; o < nbytes; o += 64) tile[o] = fidx[sym0 * 48 + o];
-            }
+            for (int o = lane; o < nw; o += 64) tile[o] = fhb[sym0 * n_words + o];
             __builtin_amdgcn_wave_barrier();
             const int t_hi = (sym0 + nsy) * n_dbps;
             for (int t0 = sym0 * n_dbps; t0 < t_hi; t0 += WR_DEC_CHUNK) {
                 const int t = t0 + lane;
                 int ra, rb;
-                gather_step(tile, sym0, tab_enc, n_dbps, recip, t, lane < WR_DEC_CHUNK && t < t_hi, ra, rb);
+                gather_step(tile, sym0, n_words, tab_enc, n_dbps, recip, t, lane < WR_DEC_CHUNK && t < t_hi, ra, rb);
                 const uint64_t A1 = __ballot(ra == 1), AV = __ballot(ra != 2);
                 const uint64_t B1 = __ballot(rb == 1), BV = __ballot(rb != 2);
                 const int jn = t_hi - t0 < WR_DEC_CHUNK ? t_hi - t0 : WR_DEC_CHUNK;
@@ -727,29 +843,37 @@ extern "C" hipError_t wr_launch_decode_maxsteps(hipStream_t st, uint32_t n_slots
     return hipGetLastError();
 }
 
+extern "C" hipError_t wr_launch_decode_pack(hipStream_t st, uint32_t n_slots, uint32_t max_sym, const wifirx_frame* frames,
+                                            const uint8_t* idx, uint32_t psdu_stride, uint32_t* hbits, uint32_t n_steps_cap)
+{
+    if (n_slots == 0) return hipSuccess;
+    uint32_t blocks = (n_slots + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(wr::decode_pack_kernel, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, idx, psdu_stride,
+                       hbits, n_steps_cap);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
-                                       const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
-                                       size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
-                                       uint64_t* masks)
+                                       const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
+                                       size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave)
 {
     if (n_slots == 0 || n_waves == 0) return hipSuccess;
-    // the coded-bit masks of all frames first (one wave per frame, as many as fit), then the decoder proper
-    uint32_t gblocks = (n_slots + 3) / 4;
-    if (gblocks > 16384) gblocks = 16384;
-    hipLaunchKernelGGL(wr::decode_gather_kernel, dim3(gblocks), dim3(256), 0, st, n_slots, max_sym, frames, idx, psdu_stride,
-                       masks, n_steps_cap, frames_per_wave);
+    // the tasks with one rate, then those with several (each kernel skips the other's; the scratch is shared)
     uint32_t blocks = (n_waves + 3) / 4;
-    hipLaunchKernelGGL(wr::decode_kernel, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, idx, psdu,
-                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, masks);
+    hipLaunchKernelGGL(wr::decode_kernel<false>, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
+                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave);
+    hipLaunchKernelGGL(wr::decode_kernel<true>, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
+                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave);
     return hipGetLastError();
 }
 
 extern "C" hipError_t wr_launch_decode_small(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
-                                             const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
+                                             const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
                                              size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves)
 {
     if (n_slots == 0 || n_waves == 0) return hipSuccess;
-    hipLaunchKernelGGL(wr::decode_small_kernel, dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, frames, idx, psdu,
+    hipLaunchKernelGGL(wr::decode_small_kernel, dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
                        psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves);
     return hipGetLastError();
 }

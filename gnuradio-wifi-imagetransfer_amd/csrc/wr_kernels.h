@@ -41,6 +41,7 @@ struct DemodOut {
     float2*       carrier;
     float2*       csi;
     float4*       sym_stats;    // per frame: sum |y|, sum |y|^2, sum |y|^4 over its equalised data symbols, 0
+    uint32_t*     hbits;        // the decisions as bit planes, max_sym * 12 words per frame (wifirx_out.hbits)
 };
 
 // one detected frame of a continuous stream (stream mode)
@@ -61,12 +62,13 @@ hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_t
                            float noise, float cfo_max, uint64_t seed, float* cfo_out);
 hipError_t wr_launch_decode_maxsteps(hipStream_t st, uint32_t n_slots, uint32_t max_sym,
                                      const wifirx_frame* frames, uint32_t psdu_stride, uint32_t* out);
+hipError_t wr_launch_decode_pack(hipStream_t st, uint32_t n_slots, uint32_t max_sym, const wifirx_frame* frames,
+                                 const uint8_t* idx, uint32_t psdu_stride, uint32_t* hbits, uint32_t n_steps_cap);
 hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
-                            const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
-                            size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
-                            uint64_t* masks);
+                            const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
+                            size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave);
 hipError_t wr_launch_decode_small(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
-                                  const uint8_t* idx, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
+                                  const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
                                   size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves);
 hipError_t wr_launch_stream_detect(hipStream_t st, const float2* x, int64_t n_samp, int64_t tile0,
                                    int64_t n_tiles, float thr, uint64_t* masks, float2* A);

@@ -153,7 +153,7 @@ __device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n
 // batch kernel: one wave = 4 consecutive slots, WR_WAVES_PER_BLOCK waves per workgroup.
 // Preamble phase per slot with the whole wave (lane = sample / lag), then the four frames walk their
 // symbols together (wr_quad.h).
-template <int EQ>
+template <int EQ, bool HB>
 __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ == WIFIRX_EQ_STA ? WR_DEMOD_WAVES_PER_SIMD_STA : WR_DEMOD_WAVES_PER_SIMD)
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
                         DemodParams prm, DemodOut out, const uint64_t* __restrict__ slot_off)
@@ -209,7 +209,7 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
     if ((lane & 15) == 0 && seed.out >= 0) { wifirx_frame* frames = out.frames; frames[seed.out].flags = seed.flags; frames[seed.out].frame_start = seed.fs; frames[seed.out].cfo_fine = seed.cfo_f; frames[seed.out].trigger = (int)seed.t; }
     return;
 #endif
-    frames_quad<EQ>(seed, prm, lds[wave], lane, out);
+    frames_quad<EQ, HB>(seed, prm, lds[wave], lane, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -238,7 +238,7 @@ void stream_detect_kernel(const float2* __restrict__ x, long n_samp, long tile0,
 }
 
 // one wave per four selected triggers of the stream
-template <int EQ>
+template <int EQ, bool HB>
 __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ == WIFIRX_EQ_STA ? WR_DEMOD_WAVES_PER_SIMD_STA : WR_DEMOD_WAVES_PER_SIMD)
 void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const StreamTrig* __restrict__ trig,
                          uint32_t n_trig, DemodParams prm, const float2* __restrict__ A, DemodOut out)
@@ -274,7 +274,7 @@ void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const Stream
         preamble_pair_finish(pf[2 * p], pf[2 * p + 1], p, lds[wave], lane, seed);
         __builtin_amdgcn_wave_barrier();
     }
-    frames_quad<EQ>(seed, prm, lds[wave], lane, out);
+    frames_quad<EQ, HB>(seed, prm, lds[wave], lane, out);
 }
 
 }  // namespace wr
@@ -285,12 +285,16 @@ extern "C" hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, ui
 {
     if (n_slots == 0) return hipSuccess;
     dim3 grid((n_slots + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
+#define WR_LAUNCH_BATCH(EQ, HB) hipLaunchKernelGGL((wr::demod_batch_kernel<EQ, HB>), grid, block, 0, st, iq, slot_len, n_slots, *prm, *out, slot_off)
+#define WR_LAUNCH_BATCH_EQ(EQ) { if (out->hbits) WR_LAUNCH_BATCH(EQ, true); else WR_LAUNCH_BATCH(EQ, false); }
     switch (prm->chan_est) {
-    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out, slot_off); break;
-    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out, slot_off); break;
-    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out, slot_off); break;
-    default:             hipLaunchKernelGGL(wr::demod_batch_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, iq, slot_len, n_slots, *prm, *out, slot_off); break;
+    case WIFIRX_EQ_LMS:  WR_LAUNCH_BATCH_EQ(WIFIRX_EQ_LMS) break;
+    case WIFIRX_EQ_COMB: WR_LAUNCH_BATCH_EQ(WIFIRX_EQ_COMB) break;
+    case WIFIRX_EQ_STA:  WR_LAUNCH_BATCH_EQ(WIFIRX_EQ_STA) break;
+    default:             WR_LAUNCH_BATCH_EQ(WIFIRX_EQ_LS) break;
     }
+#undef WR_LAUNCH_BATCH_EQ
+#undef WR_LAUNCH_BATCH
     return hipGetLastError();
 }
 
@@ -309,11 +313,15 @@ extern "C" hipError_t wr_launch_demod_stream(hipStream_t st, const float2* x, in
 {
     if (n_trig == 0) return hipSuccess;
     dim3 grid((n_trig + 4 * WR_WAVES_PER_BLOCK - 1) / (4 * WR_WAVES_PER_BLOCK)), block(64 * WR_WAVES_PER_BLOCK);
+#define WR_LAUNCH_STREAM(EQ, HB) hipLaunchKernelGGL((wr::demod_stream_kernel<EQ, HB>), grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, *out)
+#define WR_LAUNCH_STREAM_EQ(EQ) { if (out->hbits) WR_LAUNCH_STREAM(EQ, true); else WR_LAUNCH_STREAM(EQ, false); }
     switch (prm->chan_est) {
-    case WIFIRX_EQ_LMS:  hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_LMS>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, *out); break;
-    case WIFIRX_EQ_COMB: hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_COMB>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, *out); break;
-    case WIFIRX_EQ_STA:  hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_STA>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, *out); break;
-    default:             hipLaunchKernelGGL(wr::demod_stream_kernel<WIFIRX_EQ_LS>, grid, block, 0, st, x, (long)n_samp, trig, n_trig, *prm, A, *out); break;
+    case WIFIRX_EQ_LMS:  WR_LAUNCH_STREAM_EQ(WIFIRX_EQ_LMS) break;
+    case WIFIRX_EQ_COMB: WR_LAUNCH_STREAM_EQ(WIFIRX_EQ_COMB) break;
+    case WIFIRX_EQ_STA:  WR_LAUNCH_STREAM_EQ(WIFIRX_EQ_STA) break;
+    default:             WR_LAUNCH_STREAM_EQ(WIFIRX_EQ_LS) break;
     }
+#undef WR_LAUNCH_STREAM_EQ
+#undef WR_LAUNCH_STREAM
     return hipGetLastError();
 }

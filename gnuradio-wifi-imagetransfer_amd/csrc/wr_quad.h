@@ -436,6 +436,46 @@ __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrie
     }
 }
 
+// OR over the 16 lanes of a row, every lane gets the result (xor 1, xor 2, half mirror, mirror: all DPP)
+__device__ __forceinline__ uint32_t row_or16(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);
+    return v;
+}
+
+#define WR_HB_DATA_LO 0xFDFFF7C0u     // bins 6..31 without the pilots 11, 25
+#define WR_HB_DATA_HI 0x07DFFF7Eu     // bins 33..58 without the pilots 39, 53 (bit k = bin 32 + k)
+
+// a6 as bit planes (wifirx_out.hbits): word 2 b + h of the symbol = bit b of the decisions of bins 32 h .. 32 h + 31.
+// Lane r of the row holds bins r + 16 j: its bits go to position r (j even) / 16 + r (j odd) of the word of half
+// h = j >> 1, the row is OR-ed together, lane 0 stores.  hb = the frame's first word.
+template <int NB>
+__device__ __forceinline__ void store_hbits(const c32 (&Y)[4], bool ok, int q, uint32_t* __restrict__ hb, int r)
+{
+    const uint32_t p01 = (uint32_t)decide(Y[0], NB) | ((uint32_t)decide(Y[1], NB) << 16);
+    const uint32_t p23 = (uint32_t)decide(Y[2], NB) | ((uint32_t)decide(Y[3], NB) << 16);
+    uint32_t* dst = hb + (unsigned)(q * 2 * NB);
+    if (NB == 1) {
+        const uint32_t w0 = row_or16((p01 & 0x00010001u) << r) & WR_HB_DATA_LO;
+        const uint32_t w1 = row_or16((p23 & 0x00010001u) << r) & WR_HB_DATA_HI;
+        if (ok && r == 0) *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
+    } else {
+        // two planes (four words) at a time: what is live stays small
+#pragma unroll
+        for (int b = 0; b < NB; b += 2) {
+            uint4 w;
+            w.x = row_or16(((p01 >> b) & 0x00010001u) << r) & WR_HB_DATA_LO;
+            w.y = row_or16(((p23 >> b) & 0x00010001u) << r) & WR_HB_DATA_HI;
+            w.z = row_or16(((p01 >> (b + 1)) & 0x00010001u) << r) & WR_HB_DATA_LO;
+            w.w = row_or16(((p23 >> (b + 1)) & 0x00010001u) << r) & WR_HB_DATA_HI;
+            if (ok && r == 0) *reinterpret_cast<uint4*>(dst + 2 * b) = w;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // a3 copy + a4 + a5 + a6 + a7 for the four frames of a wave.
 // the constellation point of an index (levels formed in float32 as the upstream constellations do)
@@ -469,7 +509,9 @@ __device__ __forceinline__ c32 point_of(unsigned idx, int n_bpsc)
 // EQ = WIFIRX_EQ_LMS:  decision-directed (ieee802_11.LMS): Y = X/H, then H = H/2 + (X/point)/2 on every data bin.
 // EQ = WIFIRX_EQ_COMB: the four pilots of every symbol, interpolated over the band, smoothed over time.
 // EQ = WIFIRX_EQ_STA:  spectral-temporal averaging of the per-bin estimates X/point.
-template <int EQ>
+// HB: the decisions also leave as bit planes (DemodOut.hbits); a template parameter so that the kernels without planes
+// keep their register allocation.
+template <int EQ, bool HB>
 __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodParams& prm, float* qlds, int lane,
                                             const DemodOut& dout)
 {
@@ -479,6 +521,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     float2* __restrict__ car_all = dout.carrier;
     float2* __restrict__ csi_all = dout.csi;
     float4* __restrict__ stat_all = dout.sym_stats;
+    uint32_t* __restrict__ hb_all = dout.hbits;
     constexpr bool LMS = EQ == WIFIRX_EQ_LMS, COMB = EQ == WIFIRX_EQ_COMB, STA = EQ == WIFIRX_EQ_STA;
     constexpr bool DIV = EQ != WIFIRX_EQ_LS;         // Y = X / H by division (LS multiplies by G = conj(H)/|H|^2)
     const int row = lane >> 4, r = lane & 15;
@@ -878,6 +921,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 // the LLR stores are picked by one scalar branch; mixed rows take the per-constellation passes.
                 const int q = s - 3;
                 const bool has_idx = idx_all != nullptr, has_car = car_all != nullptr;
+                int out_l = out;                                  // the row's plane words are addressed from the record index
+                asm volatile("" : "+v"(out_l));                   // every symbol anew: no loop-invariant pointer in registers
                 const int nbu = __builtin_amdgcn_readfirstlane(n_bpsc);      // the loop ran: some lane is active, but
                 const bool uniform = __all(!act || n_bpsc == nbu) && __builtin_amdgcn_readfirstlane((int)act);
                 float wq[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
@@ -888,7 +933,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 }
 #define WR_STORE(NB, OK)                                                                                        \
                 { if (csi) store_bins<NB, true>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq);      \
-                  else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq); }
+                  else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq);     \
+                  if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
+                            store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
                 if (uniform) {
                     if (nbu == 1)      WR_STORE(1, act)
                     else if (nbu == 2) WR_STORE(2, act)

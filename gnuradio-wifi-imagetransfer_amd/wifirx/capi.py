@@ -14,7 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WIFIRX_LIB") or os.path.join(_HERE, "libwifirx.so")     # WIFIRX_LIB: A/B builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+DECODE_INPUT = "planes"      # what demod_batch(decode=True) hands decode_mac: "planes" (wifirx_out.hbits) or "idx"
 EQ_LS, EQ_LMS, EQ_COMB, EQ_STA = 0, 1, 2, 3
 P_BANDWIDTH, P_FREQUENCY, P_SENSITIVITY, P_CHAN_EST, P_STREAM_BATCH, P_DECODE_SMALL_MAX, P_LLR_CSI, P_STREAM_IDX = 1, 2, 3, 4, 5, 6, 7, 8
 F_DETECTED, F_SYNC, F_SIGNAL, F_COMPLETE, F_LLR, F_DECODED, F_CRC_OK = 1, 2, 4, 8, 16, 32, 64
@@ -51,7 +52,7 @@ class Config(C.Structure):
 class Out(C.Structure):
     _fields_ = [("frames", C.c_void_p), ("idx", C.c_void_p), ("llr", C.c_void_p), ("carrier", C.c_void_p),
                 ("psdu", C.c_void_p), ("psdu_stride", C.c_uint32), ("on_device", C.c_uint32), ("csi", C.c_void_p),
-                ("sym_stats", C.c_void_p)]
+                ("sym_stats", C.c_void_p), ("hbits", C.c_void_p)]
 
 
 class PollOut(C.Structure):
@@ -189,7 +190,7 @@ class WifiRx:
 
     # -- batch mode, host buffers (PCIe-bound convenience path) --
     def demod_batch(self, iq: np.ndarray, slot_len: int, decode=False, psdu_stride=2048, want_csi=False,
-                    want_stats=False) -> dict:
+                    want_stats=False, want_hbits=False) -> dict:
         iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
         n_slots = iq.size // slot_len
         assert n_slots * slot_len == iq.size
@@ -202,12 +203,17 @@ class WifiRx:
         if not decode:
             csi = np.zeros((n_slots, 52), dtype=np.complex64) if want_csi else None
             stats = np.zeros((n_slots, 4), dtype=np.float32) if want_stats else None
-            out = Out(_np_ptr(frames), _np_ptr(idx), _np_ptr(llr), _np_ptr(car), None, 0, 0, _np_ptr(csi), _np_ptr(stats))
+            hbits = np.zeros((n_slots, ms * 12), dtype=np.uint32) if want_hbits else None
+            out = Out(_np_ptr(frames), _np_ptr(idx), _np_ptr(llr), _np_ptr(car), None, 0, 0, _np_ptr(csi), _np_ptr(stats),
+                      _np_ptr(hbits))
             self._check(_lib.wifirx_demod_batch(self._h, _np_ptr(iq), 0, slot_len, n_slots, C.byref(out)))
-            return dict(frames=frames, idx=idx, llr=llr, carrier=car, psdu=None, csi=csi, sym_stats=stats)
+            return dict(frames=frames, idx=idx, llr=llr, carrier=car, psdu=None, csi=csi, sym_stats=stats, hbits=hbits)
         # decode needs the decisions on the device: run on device buffers, then download
         d_iq = self.alloc(iq.nbytes).upload(iq)
-        dev = self.alloc_out(n_slots, psdu_stride=psdu_stride, want_csi=want_csi, want_stats=want_stats)
+        # decode_mac reads the decisions as bit planes written by the demod kernel (DECODE_INPUT = "planes"), or -- for
+        # callers that only hold `idx` -- packs them itself ("idx")
+        dev = self.alloc_out(n_slots, psdu_stride=psdu_stride, want_csi=want_csi, want_stats=want_stats,
+                             want_hbits=want_hbits or DECODE_INPUT == "planes")
         try:
             self.demod_batch_dev(d_iq.ptr, slot_len, n_slots, dev)
             self.decode_batch_dev(n_slots, dev)
@@ -233,29 +239,31 @@ class WifiRx:
         return dict(frames=frames, idx=idx, llr=llr, carrier=car)
 
     # -- batch mode, device buffers (the measured path) --
-    def alloc_out(self, n_slots, psdu_stride=0, want_csi=False, want_stats=False) -> dict:
+    def alloc_out(self, n_slots, psdu_stride=0, want_csi=False, want_stats=False, want_hbits=False, want_idx=True) -> dict:
         ms = self.cfg.max_sym
         d = dict(n_slots=n_slots, psdu_stride=psdu_stride)
         d["csi"] = self.alloc(n_slots * 52 * 8) if want_csi else None
         d["sym_stats"] = self.alloc(n_slots * 16) if want_stats else None
         d["frames"] = self.alloc(n_slots * 32)
-        d["idx"] = self.alloc(n_slots * ms * 48)
+        d["idx"] = self.alloc(n_slots * ms * 48) if want_idx else None
+        d["hbits"] = self.alloc(n_slots * ms * 48) if want_hbits else None
         d["llr"] = self.alloc(n_slots * ms * 48 * self.cfg.llr_bits * 4) if self.cfg.llr_bits else None
         d["carrier"] = self.alloc(n_slots * ms * 48 * 8) if self.cfg.want_carrier else None
         d["psdu"] = self.alloc(n_slots * psdu_stride) if psdu_stride else None
-        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi", "sym_stats"):      # the kernels only write what a frame fills
+        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi", "sym_stats", "hbits"):      # the kernels only write what a frame fills
             if d[k] is not None and d[k].nbytes:
                 d[k].upload(np.zeros(d[k].nbytes, dtype=np.uint8))
         return d
 
     def free_out(self, dev):
-        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi", "sym_stats"):
+        for k in ("frames", "idx", "llr", "carrier", "psdu", "csi", "sym_stats", "hbits"):
             if dev.get(k) is not None:
                 dev[k].free()
 
     def _out_struct(self, dev) -> Out:
         g = lambda k: dev[k].ptr if dev.get(k) is not None else None
-        return Out(g("frames"), g("idx"), g("llr"), g("carrier"), g("psdu"), dev.get("psdu_stride", 0), 1, g("csi"), g("sym_stats"))
+        return Out(g("frames"), g("idx"), g("llr"), g("carrier"), g("psdu"), dev.get("psdu_stride", 0), 1, g("csi"), g("sym_stats"),
+                   g("hbits"))
 
     def demod_batch_dev(self, iq_ptr, slot_len, n_slots, dev):
         out = self._out_struct(dev)
@@ -273,9 +281,12 @@ class WifiRx:
 
     def download_out(self, dev, n_slots) -> dict:
         ms = self.cfg.max_sym
-        r = dict(frames=dev["frames"].download(FRAME_DTYPE, n_slots),
-                 idx=dev["idx"].download(np.uint8, n_slots * ms * 48).reshape(n_slots, ms, 48),
-                 llr=None, carrier=None, psdu=None, csi=None, sym_stats=None)
+        r = dict(frames=dev["frames"].download(FRAME_DTYPE, n_slots), idx=None,
+                 llr=None, carrier=None, psdu=None, csi=None, sym_stats=None, hbits=None)
+        if dev.get("idx") is not None:
+            r["idx"] = dev["idx"].download(np.uint8, n_slots * ms * 48).reshape(n_slots, ms, 48)
+        if dev.get("hbits") is not None:
+            r["hbits"] = dev["hbits"].download(np.uint32, n_slots * ms * 12).reshape(n_slots, ms * 12)
         if dev.get("sym_stats") is not None:
             r["sym_stats"] = dev["sym_stats"].download(np.float32, n_slots * 4).reshape(n_slots, 4)
         if dev.get("csi") is not None:

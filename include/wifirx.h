@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define WIFIRX_ABI_VERSION 3
+#define WIFIRX_ABI_VERSION 4
 
 /* error codes */
 #define WIFIRX_OK        0
@@ -156,6 +156,15 @@ typedef struct wifirx_out {
                                    frame's n_sym_out data symbols (48 each), 0 -- the statistics a
                                    digital.probe_mpsk_snr_est_c fed from frame_equalizer's `symbols` port accumulates
                                    (gnu_radio/IRS_AP.py:275,312); float32 sums in the order of DESIGN.md rule 13 */
+    uint32_t*     hbits;        /* ABI 4: [n_slots][max_sym * 12] -- the hard decisions of `idx` as bit planes, the form
+                                   wifirx_decode_batch reads (decode_mac's input, gnu_radio/IRS_AP.py:272).  Data symbol
+                                   q of a frame with n_bpsc bits per carrier occupies the 2 * n_bpsc words from
+                                   q * 2 * n_bpsc on (symbols are packed; 48 bytes per symbol are reserved, as for
+                                   `idx`); word 2 b + h holds bit b of the decisions of the FFT bins 32 h .. 32 h + 31
+                                   (shifted order: bin 32 = DC; data carrier c of `idx` is bin c + 6 + the pilots / DC
+                                   below it), bin 32 h + k in bit k, 0 for bins that carry no data.  Optional: when
+                                   given, wifirx_demod_batch fills it and wifirx_decode_batch reads it instead of
+                                   `idx`; words behind a frame's last symbol are not written. */
 } wifirx_out;
 
 /* Output buffers of wifirx_poll_ex (host memory; NULL = not wanted).  Row i belongs to frame i of the call. */
@@ -208,7 +217,8 @@ int  wifirx_demod_batch_v(wifirx_handle* h, const float* iq, int iq_on_device, c
 /* decode_mac over the hard decisions of a previous wifirx_demod_batch on the same buffers
  * (ieee802_11.decode_mac, gnu_radio/IRS_AP.py:272,291-292): de-interleave, de-puncture, Viterbi
  * K=7 (133,171), descramble, CRC-32.  Sets WIFIRX_F_DECODED / WIFIRX_F_CRC_OK in out->frames
- * and writes out->psdu.  Device buffers only (out->on_device = 1).  The call waits once for the
+ * and writes out->psdu.  Input: out->hbits when given (filled by the demod call: no pass over `idx` at all), else
+ * out->idx (packed into bit planes by a pre-pass).  Device buffers only (out->on_device = 1).  The call waits once for the
  * stream (a pre-pass reads back the longest trellis of the batch to size the survivor scratch);
  * the decode kernel itself is then queued asynchronously. */
 int  wifirx_decode_batch(wifirx_handle* h, uint32_t n_slots, const wifirx_out* out);

@@ -31,10 +31,14 @@ def gpu_available():
         return False
 
 
-@pytest.fixture(params=["wave_per_frame", "frames_per_lane"])
+@pytest.fixture(params=["wave_per_frame", "frames_per_lane", "wave_per_frame_from_idx", "frames_per_lane_from_idx"])
 def decode_path(request, monkeypatch):
     """decode_mac has a latency kernel (one wave per frame, small batches) and a throughput kernel (128 frames per
-    wave); both must give the oracle's bytes.  Tests that name this fixture run once with each (the library reads
-    WIFIRX_DECODE_SMALL_MAX when a handle is created)."""
-    monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "1000000000" if request.param == "wave_per_frame" else "0")
+    wave), and reads the decisions as bit planes -- written by the demod kernel (`wifirx_out.hbits`) or, for a caller
+    that only holds `idx`, packed by a pre-pass: all four combinations must give the oracle's bytes.  Tests that name
+    this fixture run once with each (the library reads WIFIRX_DECODE_SMALL_MAX when a handle is created; capi.DECODE_INPUT
+    says which buffers demod_batch(decode=True) hands over)."""
+    from wifirx import capi
+    monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "1000000000" if request.param.startswith("wave_per_frame") else "0")
+    monkeypatch.setattr(capi, "DECODE_INPUT", "idx" if request.param.endswith("_from_idx") else "planes")
     return request.param

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 18 and set(syms) == set(capi.EXPORTS)
     for s in syms:
         assert hasattr(capi.lib(), s), s
-    assert capi.lib().wifirx_abi_version() == capi.ABI_VERSION == 3
+    assert capi.lib().wifirx_abi_version() == capi.ABI_VERSION == 4
 
 
 def test_record_layouts():
@@ -37,7 +37,7 @@ def test_record_layouts():
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
     assert sizes == [32, ctypes.sizeof(capi.Config), ctypes.sizeof(capi.Out), ctypes.sizeof(capi.Stats),
-                     ctypes.sizeof(capi.PollOut)] == [32, 56, 64, 48, 56]
+                     ctypes.sizeof(capi.PollOut)] == [32, 56, 72, 48, 56]
     from oracle import oracle
     assert oracle.FRAME_DTYPE == capi.FRAME_DTYPE
 
