@@ -69,7 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--decode", action="store_true", help="put decode_mac (and the all-gather) INSIDE every timed step")
     ap.add_argument("--pdu-steps", type=int, default=2, help="steps of the separate decode_mac + all-gather leg (0 = skip)")
     ap.add_argument("--gather-chunks", type=int, default=2, help="frame ranges the PDU all-gather is cut into (N > 1)")
-    ap.add_argument("--host-samples", type=int, default=24_000_000, help="samples pushed through work() in the host_path leg")
+    ap.add_argument("--host-samples", type=int, default=96_000_000, help="samples pushed through work() in the host_path leg")
     return ap.parse_args(argv)
 
 
@@ -183,6 +183,10 @@ def main():
                    psdu_t.data_ptr() if want_pdus else None, PSDU_STRIDE if want_pdus else 0, 1, None)
     out_hb = capi.Out(frames_t.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), None,
                       psdu_t.data_ptr(), PSDU_STRIDE, 1, None, None, hbits_t.data_ptr()) if want_pdus else None
+    if os.environ.get("WIFIRX_BENCH_PLANES") and want_pdus:      # experiment switch: time the demod kernel that also writes the planes
+        out = out_hb
+    if os.environ.get("WIFIRX_BENCH_NOIDX"):                     # experiment switch: what the four byte stores per symbol cost
+        out.idx = None
     gather = None
     if world > 1 and want_pdus:
         gather = wdist.ChunkedPduGather(n_frames, PSDU_STRIDE, args.gather_chunks, coll_dev)
@@ -451,10 +455,19 @@ def main():
             t = time.perf_counter()
             grshim.run_stream(blk, xs, chunk=8192)
             dth = time.perf_counter() - t
+            n_pdu = len(got) - n0
+            # the same calls with PDU publication switched off: what work() itself sustains (staging copy, PCIe, device
+            # pipeline on the library's worker thread); the difference is Python building one PDU per frame
+            blk._publish = lambda: None
+            t = time.perf_counter()
+            grshim.run_stream(blk, xs, chunk=8192, finish=False)
+            dtw = time.perf_counter() - t
             result["host_path"] = {"gsamples_per_s": xs.size / dth / 1e9, "work_chunk_items": 8192, "samples": int(xs.size),
-                                   "pdus": len(got) - n0, "frames_in": n_host,
-                                   "note": "wifi_phy_rx.work() with pageable host chunks: PCIe copy, detection, frame kernel, "
-                                           "decode_mac, PDU construction in Python; never `value`"}
+                                   "pdus": n_pdu, "frames_in": n_host,
+                                   "work_only_gsamples_per_s": xs.size / dtw / 1e9,
+                                   "note": "wifi_phy_rx.work() with pageable host chunks: staging copy, PCIe, detection, frame "
+                                           "kernel, decode_mac, one Python PDU per frame (a frame every 4608 samples); "
+                                           "work_only = the same calls without building PDUs; never `value`"}
             blk.close()
 
         # ---- config 2, CFO = 0 variant: same frames and noise law, no carrier offset ----

@@ -2,6 +2,7 @@
 // Host side only: handles, the per-handle HIP stream, workspaces, host<->device staging.
 // No CPU compute fallback exists: every entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
+#include <emmintrin.h>      // SSE2 streaming stores of the staging copy (x86-64 baseline)
 
 #include <algorithm>
 #include <chrono>

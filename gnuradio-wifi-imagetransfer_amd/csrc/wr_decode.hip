@@ -438,13 +438,8 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                 if (tt_u == nd_u) { tt_u = 0; sym_u++; }
                 if (tt_u == 0 && (sym_u & (sym_blk - 1)) == 0) {
                     const bool okA = tg < n_data[0], okB = tg < n_data[1];
-#ifdef WR_DEC_EXP_COMPACT       /* experiment: all staging loads from one small, always cached region (results are garbage) */
-                    const uint32_t* pa = hbits_all + lane * 16 + (sym_u & 7) * 2048;
-                    const uint32_t* pb = pa + 1024;
-#else
                     const uint32_t* pa = hb_task + offA + (uint32_t)(sym_u * nw_u);
                     const uint32_t* pb = hb_task + offB + (uint32_t)(sym_u * nw_u);
-#endif
                     const uint32_t room = hb_stride - (uint32_t)(sym_u * nw_u);      // words left in a frame's row
 #pragma unroll
                     for (int k = 0; k < 16; k += 4) {

@@ -436,42 +436,64 @@ __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrie
     }
 }
 
-// OR over the 16 lanes of a row, every lane gets the result (xor 1, xor 2, half mirror, mirror: all DPP)
-__device__ __forceinline__ uint32_t row_or16(uint32_t v)
-{
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);
-    return v;
-}
-
 #define WR_HB_DATA_LO 0xFDFFF7C0u     // bins 6..31 without the pilots 11, 25
 #define WR_HB_DATA_HI 0x07DFFF7Eu     // bins 33..58 without the pilots 39, 53 (bit k = bin 32 + k)
 
+// decision bit B of a point for constellation NB -- the comparisons of decide(), one at a time
+template <int NB, int B>
+__device__ __forceinline__ bool decide_bit(c32 y)
+{
+    const float are = __builtin_fabsf(y.re), aim = __builtin_fabsf(y.im);
+    if (NB == 1) return y.re > 0.0f;
+    if (NB == 2) return B == 0 ? y.re > 0.0f : y.im > 0.0f;
+    if (NB == 4) return B == 0 ? y.re > 0.0f : B == 1 ? are < WR_T16_2 : B == 2 ? y.im > 0.0f : aim < WR_T16_2;
+    return B == 0 ? y.re > 0.0f : B == 1 ? are < WR_T64_4 : B == 2 ? (are < WR_T64_6) && (are > WR_T64_2)
+         : B == 3 ? y.im > 0.0f : B == 4 ? aim < WR_T64_4 : (aim < WR_T64_6) && (aim > WR_T64_2);
+}
+
+// the two words of bit plane B (bins 0..31, 32..63) of the four frames of the wave, into lanes 0, 16, 32, 48 of w0 / w1.
+// A comparison over the wave IS the plane: its result mask holds, for the row of frame f, bins 16 j .. 16 j + 15 in bits
+// 16 f .. 16 f + 15 when every lane compares its bin r + 16 j; the scalar unit cuts the four masks (j = 0..3) into the
+// frames' words, one write per frame puts them into the lane that stores.
+template <int NB, int B>
+__device__ __forceinline__ void plane_words(const c32 (&Y)[4], uint32_t& w0, uint32_t& w1)
+{
+    const uint64_t m0 = __ballot(decide_bit<NB, B>(Y[0])), m1 = __ballot(decide_bit<NB, B>(Y[1]));
+    const uint64_t m2 = __ballot(decide_bit<NB, B>(Y[2])), m3 = __ballot(decide_bit<NB, B>(Y[3]));
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const uint32_t lo = (uint32_t)((m0 >> (16 * f)) & 0xffffu) | ((uint32_t)((m1 >> (16 * f)) & 0xffffu) << 16);
+        const uint32_t hi = (uint32_t)((m2 >> (16 * f)) & 0xffffu) | ((uint32_t)((m3 >> (16 * f)) & 0xffffu) << 16);
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(w0) : "s"(lo & WR_HB_DATA_LO), "n"(16 * f));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(w1) : "s"(hi & WR_HB_DATA_HI), "n"(16 * f));
+    }
+}
+
 // a6 as bit planes (wifirx_out.hbits): word 2 b + h of the symbol = bit b of the decisions of bins 32 h .. 32 h + 31.
-// Lane r of the row holds bins r + 16 j: its bits go to position r (j even) / 16 + r (j odd) of the word of half
-// h = j >> 1, the row is OR-ed together, lane 0 stores.  hb = the frame's first word.
+// Lane 0 of a row stores the row's words; hb = the frame's first word.
 template <int NB>
 __device__ __forceinline__ void store_hbits(const c32 (&Y)[4], bool ok, int q, uint32_t* __restrict__ hb, int r)
 {
-    const uint32_t p01 = (uint32_t)decide(Y[0], NB) | ((uint32_t)decide(Y[1], NB) << 16);
-    const uint32_t p23 = (uint32_t)decide(Y[2], NB) | ((uint32_t)decide(Y[3], NB) << 16);
     uint32_t* dst = hb + (unsigned)(q * 2 * NB);
     if (NB == 1) {
-        const uint32_t w0 = row_or16((p01 & 0x00010001u) << r) & WR_HB_DATA_LO;
-        const uint32_t w1 = row_or16((p23 & 0x00010001u) << r) & WR_HB_DATA_HI;
+        uint32_t w0 = 0, w1 = 0;
+        plane_words<1, 0>(Y, w0, w1);
         if (ok && r == 0) *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
     } else {
         // two planes (four words) at a time: what is live stays small
-#pragma unroll
-        for (int b = 0; b < NB; b += 2) {
-            uint4 w;
-            w.x = row_or16(((p01 >> b) & 0x00010001u) << r) & WR_HB_DATA_LO;
-            w.y = row_or16(((p23 >> b) & 0x00010001u) << r) & WR_HB_DATA_HI;
-            w.z = row_or16(((p01 >> (b + 1)) & 0x00010001u) << r) & WR_HB_DATA_LO;
-            w.w = row_or16(((p23 >> (b + 1)) & 0x00010001u) << r) & WR_HB_DATA_HI;
-            if (ok && r == 0) *reinterpret_cast<uint4*>(dst + 2 * b) = w;
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        plane_words<NB, 0>(Y, w.x, w.y);
+        plane_words<NB, 1>(Y, w.z, w.w);
+        if (ok && r == 0) *reinterpret_cast<uint4*>(dst) = w;
+        if (NB >= 4) {
+            plane_words<NB, 2>(Y, w.x, w.y);
+            plane_words<NB, (NB >= 4 ? 3 : 0)>(Y, w.z, w.w);
+            if (ok && r == 0) *reinterpret_cast<uint4*>(dst + 4) = w;
+        }
+        if (NB == 6) {
+            plane_words<NB, (NB == 6 ? 4 : 0)>(Y, w.x, w.y);
+            plane_words<NB, (NB == 6 ? 5 : 0)>(Y, w.z, w.w);
+            if (ok && r == 0) *reinterpret_cast<uint4*>(dst + 8) = w;
         }
     }
 }

@@ -172,12 +172,19 @@ class wifi_phy_rx(grshim.sync_block):
             psdu = r["psdu"]
             freq = self.frequency
             csi = r["csi"] if self.publish_csi else None
+            p_mac = self._p_mac
+            if csi is None and not grshim.HAVE_GNURADIO:
+                # the common case on the shim, kept tight: a PDU is (dict, row view) -- poll() handed out its own copy of the rows
+                for i in ok:
+                    pub(p_mac, ({"frame_bytes": plen[i], "encoding": enc[i], "snr": snr[i], "freq": freq,
+                                 "freq_offset": foff[i], "dlt": LINKTYPE_IEEE802_11}, psdu[i, :plen[i] - 4]))
+                continue
             for i in ok:
                 meta = {"frame_bytes": plen[i], "encoding": enc[i], "snr": snr[i], "freq": freq,
                         "freq_offset": foff[i], "dlt": LINKTYPE_IEEE802_11}
                 if csi is not None:
-                    meta["csi"] = csi[i].copy()
-                pub(self._p_mac, make(meta, psdu[i, :plen[i] - 4].copy()))
+                    meta["csi"] = csi[i]
+                pub(p_mac, make(meta, psdu[i, :plen[i] - 4]))
 
     def get_probe_snr(self):
         """latest estimate of the SNR probe in dB (None without a probe)"""
