@@ -5,11 +5,11 @@
 // One wavefront decodes 128 frames: lane l owns frames base + l ("A", low halves) and base + 64 + l ("B", high
 // halves).  The 64 path metrics of both frames live in 64 VGPRs as packed 16-bit pairs, and the
 // add-compare-select of all 32 butterflies of a trellis step is straight-line packed arithmetic
-// (v_pk_add_u16 / v_pk_min_u16 / v_pk_sub_i16: one instruction works on both frames, no cross-lane traffic);
+// (32-bit adds / v_pk_min_u16 / v_pk_sub_i16: one instruction works on both frames, no cross-lane traffic);
 // metrics are updated in place, which rotates the state <-> register map by one bit per step, so the code is
 // unrolled over the 6 steps after which the map is the identity again (all rates have n_data % 12 == 0).
-// The survivor bit of a state is the sign of (candidate 1 - candidate 0), shifted into a packed accumulator by
-// v_pk_lshrrev_b16 + v_pk_mad_u16; the 64 bits per frame and step leave as one 16-byte store per lane.
+// The survivor bit of a state is the sign of (candidate 1 - candidate 0), dropped into a packed accumulator by one
+// v_bfi_b32 (see acs_step); the 64 bits per frame and step leave as one 16-byte store per lane.
 // 16-bit metrics: the start penalty of the states != 0 only has to outlast the first six steps (from then on every
 // state has a survivor that started in state 0), and the common minimum is subtracted every 120 steps, so values
 // stay far below 2^15 and the signed difference orders them; decisions depend on differences only.
