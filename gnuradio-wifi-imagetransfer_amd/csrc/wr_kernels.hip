@@ -195,6 +195,12 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
             }
         }
     }
+#if WR_ABLATE == 2   // timing experiment: detection (a1 + a2) only
+    if (lane < 4) { wifirx_frame* frames = out.frames; const int f = lane; long o = f == 0 ? pf[0].out : f == 1 ? pf[1].out : f == 2 ? pf[2].out : pf[3].out;
+                    int t = f == 0 ? pf[0].t : f == 1 ? pf[1].t : f == 2 ? pf[2].t : pf[3].t; float c = f == 0 ? pf[0].cfo_c : f == 1 ? pf[1].cfo_c : f == 2 ? pf[2].cfo_c : pf[3].cfo_c;
+                    if (o >= 0) { frames[o].trigger = t; frames[o].cfo_coarse = c; } }
+    return;
+#endif
     PreSamples ps[4];
 #pragma unroll
     for (int f = 0; f < 4; f++) preamble_load(pf[f], lane, ps[f]);
