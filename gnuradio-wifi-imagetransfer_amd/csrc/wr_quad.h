@@ -402,21 +402,25 @@ __device__ __forceinline__ float row_xor_sum16(float v)
 // a6 + a7 stores of one lane's four bins for constellation NB (compile-time: no per-lane branching on it).
 // ok = row active; the pointers are the row's output slices.
 // CSI: every LLR is multiplied by w[j] = |H|^2 of its sub-carrier (spec rule 12).
+// idx / car / llr: the rows of the wave's FIRST record (wave-uniform pointers: the stores take them from scalar
+// registers); row_o / row_l: this row's distance from there in decisions / in LLR values (32 bits per lane).
 template <int NB, bool CSI>
 __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrier)[4], bool ok, int q,
                                            uint8_t* __restrict__ idx, float2* __restrict__ car,
                                            float* __restrict__ llr, bool has_idx, bool has_car, bool want_llr,
-                                           const float (&w)[4])
+                                           const float (&w)[4], uint32_t row_o, uint32_t row_l)
 {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (!(ok && carrier[j] >= 0)) continue;
-        const unsigned o = (unsigned)(q * 48 + carrier[j]);
+        const uint32_t oq = (uint32_t)(q * 48 + carrier[j]);
+        const uint32_t o = row_o + oq;
         if (has_idx) idx[o] = decide(Y[j], NB);
-        if (has_car) car[o] = make_float2(Y[j].re, Y[j].im);
+        // byte distances in 32 bits: base pointer from scalar registers + one offset register per store
+        if (has_car) *reinterpret_cast<float2*>(reinterpret_cast<char*>(car) + (uint32_t)(o * 8u)) = make_float2(Y[j].re, Y[j].im);
         if (want_llr) {
             const float are = __builtin_fabsf(Y[j].re), aim = __builtin_fabsf(Y[j].im);
-            float* lp = llr + (size_t)o * NB;
+            float* lp = reinterpret_cast<float*>(reinterpret_cast<char*>(llr) + (uint32_t)((row_l + oq * NB) * 4u));
             const float wj = CSI ? w[j] : 1.0f;
 #define WR_WT(v) (CSI ? (v) * wj : (v))
             if (NB == 1) {
@@ -638,9 +642,15 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     // transpose A: stage-1 output q of lane r=(m, c) is element (q, m, c); lane (q1=c2, m) reads (q1, m, j)
     // transpose B: stage-2 output q2 of lane (q1=c2, m) is element (q2, q1, m); lane (q1=r&3, q2=c2) reads (q2, q1, j)
     const size_t per = (size_t)prm.max_sym * 48;
-    uint8_t* idx = (idx_all && out >= 0) ? idx_all + (size_t)out * per : nullptr;
-    float*   llr = (llr_all && out >= 0) ? llr_all + (size_t)out * per * prm.llr_bits : nullptr;
-    float2*  car = (car_all && out >= 0) ? car_all + (size_t)out * per : nullptr;
+    // The rows of a wave hold consecutive records: the output rows are addressed from the wave's first record (scalar
+    // registers) plus a 32-bit distance per lane -- no 64-bit pointer per output and lane.
+    const uint64_t have_out = __ballot(out >= 0);
+    const int out_base = have_out ? __builtin_amdgcn_readlane(out, (int)__builtin_ctzll(have_out)) : 0;
+    const uint32_t row_o = out >= 0 ? (uint32_t)(out - out_base) * (uint32_t)per : 0u;
+    const uint32_t row_l = row_o * prm.llr_bits;
+    uint8_t* idx = idx_all ? idx_all + (size_t)out_base * per : nullptr;
+    float*   llr = llr_all ? llr_all + (size_t)out_base * per * prm.llr_bits : nullptr;
+    float2*  car = car_all ? car_all + (size_t)out_base * per : nullptr;
 
     for (int s = 0;; s++) {
         const int off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
@@ -954,8 +964,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                     for (int j = 0; j < 4; j++) wq[j] = Wl[64 * j];
                 }
 #define WR_STORE(NB, OK)                                                                                        \
-                { if (csi) store_bins<NB, true>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq);      \
-                  else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq);     \
+                { if (csi) store_bins<NB, true>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq, row_o, row_l);  \
+                  else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq, row_o, row_l); \
                   if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
                             store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
                 if (uniform) {
