@@ -577,8 +577,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     const float er_scale = (float)(bw / (two_pi * fc * 80));
     float d_er = 0.0f;
     // total derotation as an exact integer phase: Qp = 2^-62 quarter turns per sample; sample m has phase Qp*m
-    // mod 2^64.  `ph` holds the phase of this lane's first sample of the current symbol and advances by Qp*80
-    // (Qp*64 after the first long training symbol) -- two integer adds per symbol instead of a double product.
+    // mod 2^64 (a 64 x 32-bit product where a phasor is formed from it, spec rule 8).
     const double theta_d = (double)cfo_f - (double)cfo_c;
     const unsigned long long Qp = (unsigned long long)(long long)__builtin_rint(theta_d * WR_TWO_OVER_PI_D * 4611686018427387904.0);
     c32 u16;                                                   // exp(j theta 16)
@@ -586,8 +585,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         const unsigned long long q16 = Qp * 16ull;
         sp_sincos_q((uint32_t)(q16 >> 32), (uint32_t)q16, u16.im, u16.re);
     }
-    unsigned long long ph = Qp * (unsigned long long)(unsigned)(fs + r);
-    const unsigned long long q80 = Qp * 80ull;
+    c32 u80;                                                   // exp(j theta 80): one symbol further on
+    {
+        const unsigned long long q80 = Qp * 80ull;
+        sp_sincos_q((uint32_t)(q80 >> 32), (uint32_t)q80, u80.im, u80.re);
+    }
+    c32 wbase = { 1.0f, 0.0f };                                // phasor of this lane's first sample of the current symbol
     const float rp_qpsk = 1.0f / fma_(WR_LEVEL_QPSK, WR_LEVEL_QPSK, WR_LEVEL_QPSK * WR_LEVEL_QPSK);     // LMS / STA: 1 / |QPSK point|^2
     int n_sym = 0, n_bpsc = 1, n_out = 0, enc = 0, psdu_len = 0;
     bool have_signal = false, want_llr = false;
@@ -679,10 +682,15 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 for (int j = 0; j < 4; j++) cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
             }
         }
-        {   // one rotation by the total offset: base phasor from a double angle, then steps of exp(j theta 16)
-            c32 w;
-            sp_sincos_q((uint32_t)(ph >> 32), (uint32_t)ph, w.im, w.re);
-            ph += (s == 0) ? (q80 - Qp * 16ull) : q80;          // next symbol starts 64 (s = 0) or 80 samples later
+        {   // one rotation by the total offset (spec rule 8): the lane's base phasor from the exact integer phase at
+            // s = 0, 1, 9, 17, ..., in between carried from symbol to symbol by exp(j theta 80); then steps of exp(j theta 16)
+            if (s < 2 || ((s - 1) & 7) == 0) {                   // wave-uniform
+                const unsigned long long ph = Qp * (unsigned long long)(unsigned)(off0 + r);
+                sp_sincos_q((uint32_t)(ph >> 32), (uint32_t)ph, wbase.im, wbase.re);
+            } else {
+                wbase = sp_cmul(wbase, u80);
+            }
+            c32 w = wbase;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 v[j] = sp_cmul(cur[j], w);                         // rows without a symbol loaded zeros above

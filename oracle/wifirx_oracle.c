@@ -710,8 +710,11 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     const double theta_d = (double)cfo_f - (double)cfo_c;       /* total derotation, rad/sample */
     /* ... as an integer phase increment: 2^-62 quarter turns per sample */
     const uint64_t Qp = (uint64_t)(int64_t)rint(theta_d * WR_TWO_OVER_PI_D * 4611686018427387904.0);
-    c32 u16;                                                    /* exp(j theta 16) */
+    c32 u16, u80;                                               /* exp(j theta 16), exp(j theta 80) */
     sp_sincos_q(Qp * 16u, &u16.im, &u16.re);
+    sp_sincos_q(Qp * 80u, &u80.im, &u80.re);
+    c32 wbase[16];                                              /* phasor of the first sample of lane r of the current symbol */
+    memset(wbase, 0, sizeof wbase);
     c32 prev[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
     c32 H[64], G[64], DH[64];                                   /* DH: running estimate of COMB / STA */
     float W[64];                                                /* |H|^2 of the LS estimate: the LLR weight (llr_csi) */
@@ -732,13 +735,17 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
         /* sync_short copy + sync_long copy.  Upstream: two float rotations exp(-j cfo_c m), exp(+j cfo_f m)
          * per sample.  Spec (section 4.8): one rotation by the total offset; the phasor of sample m0 + r (r = 0..15)
          * comes from a double angle reduced in double, the samples 16, 32, 48 further on from three
-         * multiplications by the frame's exp(j theta 16).  The phase is kept as an exact integer (Q*m mod 2^64). */
+         * multiplications by the frame's exp(j theta 16).  The phase is kept as an exact integer (Q*m mod 2^64).
+         * From one symbol to the next (80 samples on, from the second long training symbol) the base phasor is carried by
+         * one multiplication with exp(j theta 80); every eighth symbol (s = 1, 9, 17, ...) it is formed from the exact
+         * phase again, so that at most seven products separate a phasor from an exact one. */
         c32 z[64], X[64];
         if (spec) {
+            const int exact = (s < 2) || (((s - 1) & 7) == 0);
             for (int r = 0; r < 16; r++) {
-                float ws, wc;
-                sp_sincos_q(Qp * (uint64_t)(off0 + r), &ws, &wc);
-                c32 w = { wc, ws };
+                if (exact) sp_sincos_q(Qp * (uint64_t)(off0 + r), &wbase[r].im, &wbase[r].re);
+                else       wbase[r] = sp_cmul(wbase[r], u80);
+                c32 w = wbase[r];
                 for (int j = 0; j < 4; j++) {
                     c32 xs = x_at(x, n_samp, t - 16 + off0 + r + 16 * j);
                     z[r + 16 * j] = sp_cmul(xs, w);
