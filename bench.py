@@ -271,6 +271,11 @@ def main():
         # the demod kernel once more, now also writing the bit planes decode_mac reads (same frames, same decisions)
         demod(out_hb)
         demod_planes_ms = float(np.median([demod(out_hb) for _ in range(3)]))
+        # what the reference's application needs -- PDUs only: the demod kernel writing nothing but the planes and the records
+        out_pdu = capi.Out(frames_t.data_ptr(), None, None, None, psdu_t.data_ptr(), PSDU_STRIDE, 1, None, None, hbits_t.data_ptr())
+        demod(out_pdu)
+        demod_pdu_only_ms = float(np.median([demod(out_pdu) for _ in range(3)]))
+        demod(out_hb)                             # the buffers as the timed configuration leaves them
         pdu_step()                                # untimed: first-call allocations (survivor scratch), communicator set-up
         barrier()
         dec_ms, ag_ms = [], []
@@ -302,6 +307,7 @@ def main():
         dec_from_idx_ms = (time.perf_counter() - t3) * 1e3
         pdu_leg = {"decode_mac_ms": float(np.median(dec_ms)),
                    "demod_with_planes_ms": demod_planes_ms, "decode_mac_from_idx_ms": dec_from_idx_ms,
+                   "demod_planes_only_ms": demod_pdu_only_ms,
                    "all_gather_ms": ag_alone, "all_gather_exposed_ms": float(np.median(ag_ms)) if world > 1 else None,
                    "gather_chunks": gather.n_chunks if gather is not None else None,
                    "ms_per_step": leg, "psdu_stride": PSDU_STRIDE,
@@ -392,8 +398,13 @@ def main():
             t_pair = pdu_leg["demod_with_planes_ms"] + pdu_leg["decode_mac_ms"]
             result["samples_to_pdu"] = {"demod_ms": pdu_leg["demod_with_planes_ms"], "decode_mac_ms": pdu_leg["decode_mac_ms"],
                                         "gsamples_per_s": float(n_frames) * SLOT_LEN / (t_pair * 1e-3) / 1e9,
+                                        "pdu_only_demod_ms": pdu_leg["demod_planes_only_ms"],
+                                        "pdu_only_gsamples_per_s": float(n_frames) * SLOT_LEN /
+                                                                   ((pdu_leg["demod_planes_only_ms"] + pdu_leg["decode_mac_ms"]) * 1e-3) / 1e9,
                                         "note": "per GPU: samples -> decoded PSDUs, device-resident: the demod kernel writing idx, LLRs "
-                                                "and the bit planes of the decisions (wifirx_out.hbits), decode_mac reading the planes"}
+                                                "and the bit planes of the decisions (wifirx_out.hbits), decode_mac reading the planes; "
+                                                "pdu_only = the demod kernel writing the planes alone (no idx, no LLRs): what the "
+                                                "reference's image transfer consumes"}
 
     # ---- cpu_baseline leg: the oracle on this host's cores, bounded sample of the same batch ----
     if rank == 0 and world == 1 and not args.no_cpu:      # contract: rank 0 at N=1 only

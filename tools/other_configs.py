@@ -34,10 +34,16 @@ def main():
         assert 160 + tx.samples.shape[1] <= slot_len
         rx = capi.WifiRx(max_sym=n_sym, llr_bits=n_bpsc)
         slots = rx.alloc(n_frames * slot_len * 8)
-        dev = rx.alloc_out(n_frames, psdu_stride=((plen + 63) // 64) * 64)
+        dev = rx.alloc_out(n_frames, psdu_stride=((plen + 63) // 64) * 64, want_hbits=True)
         rx.synth_slots(tx.samples, slots.ptr, slot_len, n_frames, 160, 25.0, 0.037, 77)
+        # the contract's outputs (idx, LLRs, records) first; then the same kernel also writing the bit planes decode_mac reads
+        planes = dev.pop("hbits")
+        dev["hbits"] = None
         rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=1)
         ms = rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=5)
+        dev["hbits"] = planes
+        rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=1)
+        ms_planes = rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=3)
         rx.decode_batch_dev(n_frames, dev); rx.sync()
         t = time.perf_counter()
         rx.decode_batch_dev(n_frames, dev); rx.sync()
@@ -46,8 +52,33 @@ def main():
         bpf = 8 * slot_len + 48 * n_sym * (1 + 4 * n_bpsc) + 32
         res.append({"case": name, "frames": n_frames, "n_sym": n_sym, "demod_ms": ms,
                     "gsamples_per_s": n_frames * slot_len / ms / 1e6, "algorithmic_bytes_per_frame": bpf,
-                    "roofline_frac": bpf * n_frames / (ms * 1e-3) / 8e12, "decode_mac_ms": dec_ms,
+                    "roofline_frac": bpf * n_frames / (ms * 1e-3) / 8e12, "demod_with_planes_ms": ms_planes, "decode_mac_ms": dec_ms,
                     "crc_ok": int(((fr["flags"] & capi.F_CRC_OK) != 0).sum())})
+        rx.free_out(dev); slots.free(); rx.close()
+    # several rates in one batch (decode_mac's per-lane look-up kernel): QPSK-1/2 and 16-QAM-3/4 frames alternate
+    if not os.environ.get("WIFIRX_ONLY_EQ"):
+        plen, slot_len = 294, 4608
+        ta = txgen.encode_psdus(txgen.make_psdus(128, plen, seed=5), 2)
+        tb = txgen.encode_psdus(txgen.make_psdus(128, plen, seed=6), 5)
+        flen = max(ta.samples.shape[1], tb.samples.shape[1])
+        tmpl = np.zeros((256, flen), np.complex64)
+        tmpl[0::2, :ta.samples.shape[1]] = ta.samples
+        tmpl[1::2, :tb.samples.shape[1]] = tb.samples
+        n_sym = max(ta.n_sym, tb.n_sym)
+        rx = capi.WifiRx(max_sym=n_sym, llr_bits=4)
+        slots = rx.alloc(n_frames * slot_len * 8)
+        dev = rx.alloc_out(n_frames, psdu_stride=320, want_hbits=True)
+        rx.synth_slots(tmpl, slots.ptr, slot_len, n_frames, 160, 25.0, 0.037, 77)
+        rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=1)
+        ms = rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=5)
+        rx.decode_batch_dev(n_frames, dev); rx.sync()
+        t = time.perf_counter()
+        rx.decode_batch_dev(n_frames, dev); rx.sync()
+        dec_ms = (time.perf_counter() - t) * 1e3
+        fr = dev["frames"].download(capi.FRAME_DTYPE, n_frames)
+        res.append({"case": "mixed rates: QPSK 1/2 and 16-QAM 3/4 frames alternate, 294 B, slot 4608", "frames": n_frames,
+                    "n_sym": [int(ta.n_sym), int(tb.n_sym)], "demod_ms": ms, "gsamples_per_s": n_frames * slot_len / ms / 1e6,
+                    "decode_mac_ms": dec_ms, "crc_ok": int(((fr["flags"] & capi.F_CRC_OK) != 0).sum())})
         rx.free_out(dev); slots.free(); rx.close()
     # the other equalisers on config 2's geometry (their kernel instances are parity-tested, not tuned)
     eqs = []
