@@ -20,7 +20,8 @@ def main():
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(src + "/p*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(
+            # template arguments stay in the name: demod_batch_kernel<EQ, planes> and decode_kernel<mixed> are different kernels
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()][r["Counter_Name"]].append(
                 float(r["Counter_Value"]))
     with open(prefix + "_pmc_summary.csv", "w") as out:
         out.write("kernel,counter,mean_per_dispatch,dispatches\n")
@@ -29,12 +30,13 @@ def main():
                 continue
             for c in sorted(acc[k]):
                 v = acc[k][c]
-                out.write("%s,%s,%.6g,%d\n" % (k, c, sum(v) / len(v), len(v)))
-    d = {c: sum(v) / len(v) for c, v in acc["wr::demod_batch_kernel"].items()}
+                out.write("\"%s\",%s,%.6g,%d\n" % (k, c, sum(v) / len(v), len(v)))
+    dom = "wr::demod_batch_kernel<0, false>"            # the timed kernel of bench.py: LS equaliser, no plane output
+    d = {c: sum(v) / len(v) for c, v in acc[dom].items()}
     corr = 2.0
     rd, wr = d["FETCH_SIZE"] * 1024 * corr, d["WRITE_SIZE"] * 1024
     traffic = {
-        "kernel": "wr::demod_batch_kernel",
+        "kernel": dom,
         "frames_per_launch": frames,
         "FETCH_SIZE_KB": d["FETCH_SIZE"],
         "WRITE_SIZE_KB": d["WRITE_SIZE"],
