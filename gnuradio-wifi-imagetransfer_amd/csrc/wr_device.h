@@ -96,6 +96,19 @@ __device__ __forceinline__ float sp_rsqrt(float v)
     return y;
 }
 
+// 1/v for normal positive v (spec rule 11): seed by negating the exponent, three Newton steps y <- y + y (1 - v y);
+// seven full-rate instructions instead of the division's ten with a quarter-rate v_rcp_f32 among them
+__device__ __forceinline__ float sp_recip(float v)
+{
+    float y = __uint_as_float(0x7EF127EAu - __float_as_uint(v));
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float e = fma_(-v, y, 1.0f);
+        y = fma_(y, e, y);
+    }
+    return y;
+}
+
 __device__ __forceinline__ float sp_atan2(float y, float x)
 {
     float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);

@@ -591,7 +591,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         sp_sincos_q((uint32_t)(q80 >> 32), (uint32_t)q80, u80.im, u80.re);
     }
     c32 wbase = { 1.0f, 0.0f };                                // phasor of this lane's first sample of the current symbol
-    const float rp_qpsk = 1.0f / fma_(WR_LEVEL_QPSK, WR_LEVEL_QPSK, WR_LEVEL_QPSK * WR_LEVEL_QPSK);     // LMS / STA: 1 / |QPSK point|^2
+    const float rp_bpsk = sp_recip(1.0f);                      // LMS / STA: 1 / |BPSK point|^2 as the rule forms it
+    const float rp_qpsk = sp_recip(fma_(WR_LEVEL_QPSK, WR_LEVEL_QPSK, WR_LEVEL_QPSK * WR_LEVEL_QPSK));     // LMS / STA: 1 / |QPSK point|^2
     int n_sym = 0, n_bpsc = 1, n_out = 0, enc = 0, psdu_len = 0;
     bool have_signal = false, want_llr = false;
     float snr = 0.0f;
@@ -860,12 +861,14 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 asm volatile("" : "+v"(carrier[j]));     // keeps base + carrier out of loop-invariant registers
                 Y[j] = { 0.0f, 0.0f };
                 HU[j] = X[j];
-                // LS: every bin is multiplied (G = 0 on unused bins; pilot bins are never stored)
-                if (!DIV || carrier[j] >= 0) {
+                // every bin is equalised, data or not (LS: G = 0 on unused bins; the others: H = 1 there from the LTS step on;
+                // pilot and unused bins are never stored, and no branch has to fence them off -- except in the STA instance,
+                // whose register allocation is the better for it: 20.1 vs 21.1 ms)
+                if (!STA || carrier[j] >= 0) {
                     const float2 g0 = DHl[64 * j];
                     if (DIV) {
                         // spec rule 11: one reciprocal of |H|^2 per bin, then products
-                        const float rd = 1.0f / fma_(g0.y, g0.y, g0.x * g0.x);
+                        const float rd = sp_recip(fma_(g0.y, g0.y, g0.x * g0.x));
                         Y[j].re = fma_(X[j].im, g0.y, X[j].re * g0.x) * rd;
                         Y[j].im = fma_(X[j].im, g0.x, -(X[j].re * g0.y)) * rd;
                         if (LMS || STA) {
@@ -874,8 +877,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                             // 1 / |point|^2: BPSK and QPSK points all have one magnitude, the quotient is formed once per wave
                             // (same value); the wave divides per bin only when a row carries 16- or 64-QAM
                             float rp;
-                            if (const_mag) rp = nbl == 1 ? 1.0f : rp_qpsk;
-                            else           rp = 1.0f / fma_(pt.im, pt.im, pt.re * pt.re);
+                            if (const_mag) rp = nbl == 1 ? rp_bpsk : rp_qpsk;
+                            else           rp = sp_recip(fma_(pt.im, pt.im, pt.re * pt.re));
                             const float tr = fma_(X[j].im, pt.im, X[j].re * pt.re) * rp;
                             const float ti = fma_(X[j].im, pt.re, -(X[j].re * pt.im)) * rp;
                             if (LMS && act) Hl[64 * j] = make_float2(0.5f * g0.x + 0.5f * tr, 0.5f * g0.y + 0.5f * ti);

@@ -182,6 +182,13 @@ def rsqrt(x):
     return r
 
 
+def recip(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    r = np.empty_like(x)
+    lib().orc_recip(_p(x), _p(r), C.c_long(x.size))
+    return r
+
+
 def fft64(x, math_mode=MATH_SPEC):
     x = np.ascontiguousarray(x, dtype=np.complex64).reshape(-1, 64)
     out = np.empty_like(x)

@@ -121,6 +121,21 @@ static inline float sp_rsqrt(float v)
     return y;
 }
 
+/* 1/v for normal positive v (spec rule 11): seed by negating the exponent, three Newton steps y <- y + y (1 - v y) */
+static inline float sp_recip(float v)
+{
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    b = 0x7EF127EAu - b;
+    float y;
+    memcpy(&y, &b, 4);
+    for (int k = 0; k < 3; k++) {
+        const float e = fmaf(-v, y, 1.0f);
+        y = fmaf(y, e, y);
+    }
+    return y;
+}
+
 static inline float sp_atan2(float y, float x)
 {
     float ax = fabsf(x), ay = fabsf(y);
@@ -922,9 +937,9 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 for (int i = 6; i <= 58; i++) if (i != 32) csi[k++] = H[i];
             }
         } else {
-            /* spec rule 11: X / H as conj(H) X times ONE reciprocal, r = 1 / |H|^2 (a correctly rounded division), then two
-             * products -- not two divisions */
-#define SP_CDIV(X_, H_, OUT_) do { const float d_ = fmaf((H_).im, (H_).im, (H_).re * (H_).re); const float r_ = 1.0f / d_;         \
+            /* spec rule 11: X / H as conj(H) X times ONE reciprocal, r = sp_recip(|H|^2) (Newton from an exponent seed: no
+             * division), then two products */
+#define SP_CDIV(X_, H_, OUT_) do { const float d_ = fmaf((H_).im, (H_).im, (H_).re * (H_).re); const float r_ = sp_recip(d_);         \
                                    (OUT_).re = fmaf((X_).im, (H_).im, (X_).re * (H_).re) * r_;                                      \
                                    (OUT_).im = fmaf((X_).im, (H_).re, -((X_).re * (H_).im)) * r_; } while (0)
             uint8_t bits48[48];
@@ -1200,6 +1215,7 @@ void orc_sincos(const float* x, float* s, float* c, long n) { for (long i = 0; i
 void orc_atan2(const float* y, const float* x, float* r, long n) { for (long i = 0; i < n; i++) r[i] = sp_atan2(y[i], x[i]); }
 void orc_log2(const float* x, float* r, long n) { for (long i = 0; i < n; i++) r[i] = sp_log2(x[i]); }
 void orc_rsqrt(const float* x, float* r, long n) { for (long i = 0; i < n; i++) r[i] = sp_rsqrt(x[i]); }
+void orc_recip(const float* x, float* r, long n) { for (long i = 0; i < n; i++) r[i] = sp_recip(x[i]); }
 void orc_fft64(const c32* in, c32* out, long n, int math_mode)
 {
     for (long i = 0; i < n; i++) {

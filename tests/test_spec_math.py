@@ -48,6 +48,17 @@ def test_rsqrt_accuracy(orc):
     assert orc.rsqrt(np.float32([1.0, 4.0, 0.25])).tolist() == pytest.approx([1.0, 0.5, 2.0], rel=2e-7)
 
 
+def test_recip_accuracy(orc):
+    """spec rule 11: three Newton steps from the exponent-negating seed"""
+    rng = np.random.default_rng(5)
+    m = (np.arange(1 << 23, dtype=np.uint32) | np.uint32(0x3F800000)).view(np.float32)         # every float of [1, 2)
+    v = np.concatenate([m, np.exp(rng.uniform(-60, 60, 1 << 20)).astype(np.float32)])
+    r = orc.recip(v).astype(np.float64)
+    rel = np.abs(r * v.astype(np.float64) - 1.0)
+    assert rel.max() < 1.5e-7, rel.max()
+    assert not np.isfinite(orc.recip(np.float32([0.0]))[0])                                   # 1/0 still is no number
+
+
 def test_fft64_spec_matches_numpy_and_libm_mode(orc):
     rng = np.random.default_rng(3)
     x = (rng.standard_normal((500, 64)) + 1j * rng.standard_normal((500, 64))).astype(np.complex64)
