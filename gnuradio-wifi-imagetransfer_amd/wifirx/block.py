@@ -141,7 +141,8 @@ class wifi_phy_rx(grshim.sync_block):
         pub, make = self.message_port_pub, grshim.make_pdu
         want_car = self.publish_carrier
         while True:
-            r = self._rx.poll(cap=1024, psdu_stride=2048, want_csi=self.publish_csi, want_stats=self.snr_probe is not None)
+            r = self._rx.poll(cap=1024, psdu_stride=2048, want_csi=self.publish_csi, want_stats=self.snr_probe is not None,
+                              trim_psdu=True)
             fr = r["frames"]
             nf = len(fr)
             if nf == 0:

@@ -311,7 +311,7 @@ class WifiRx:
         iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
         self._check(_lib.wifirx_push(self._h, _np_ptr(iq), iq.size, 0))
 
-    def poll(self, cap=256, psdu_stride=2048, want_idx=False, want_csi=False, want_stats=False):
+    def poll(self, cap=256, psdu_stride=2048, want_idx=False, want_csi=False, want_stats=False, trim_psdu=False):
         """Finished frames of the stream, oldest first (at most `cap`).  The landing buffers are kept between calls
         (a scheduler polls after every work()); what is returned are copies of the filled part."""
         ms = self.cfg.max_sym
@@ -330,6 +330,11 @@ class WifiRx:
         n = C.c_uint32(0)
         self._check(_lib.wifirx_poll_ex(self._h, C.byref(self._poll_out), cap, C.byref(n)))
         n = n.value
-        return dict(frames=frames[:n].copy(), psdu=psdu[:n].copy(), idx=None if idx is None else idx[:n].copy(),
+        # trim_psdu: the rows are cut to the longest PSDU of the call before they are copied (a frame usually fills a fraction
+        # of its 2048-byte row; the block polls this way)
+        w = psdu_stride
+        if trim_psdu and n:
+            w = min(max(int(frames["psdu_len"][:n].max()), 1), psdu_stride)
+        return dict(frames=frames[:n].copy(), psdu=psdu[:n, :w].copy(), idx=None if idx is None else idx[:n].copy(),
                     carrier=None if car is None else car[:n].copy(), csi=None if csi is None else csi[:n].copy(),
                     sym_stats=None if stats is None else stats[:n].copy())
