@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ == WIFIRX_EQ_STA ? WR_D
 void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32_t n_slots,
                         DemodParams prm, DemodOut out, const uint64_t* __restrict__ slot_off)
 {
-    __shared__ __attribute__((aligned(16))) float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
+    __shared__ __attribute__((aligned(16))) float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ) > WR_QLDS_PRE_FLOATS ? WR_QLDS_FLOATS_EQ(EQ) : WR_QLDS_PRE_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t slot0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * WR_WAVES_PER_BLOCK, EQ == WIFIRX_EQ_STA ? WR_D
 void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const StreamTrig* __restrict__ trig,
                          uint32_t n_trig, DemodParams prm, const float2* __restrict__ A, DemodOut out)
 {
-    __shared__ __attribute__((aligned(16))) float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ)];
+    __shared__ __attribute__((aligned(16))) float lds[WR_WAVES_PER_BLOCK][WR_QLDS_FLOATS_EQ(EQ) > WR_QLDS_PRE_FLOATS ? WR_QLDS_FLOATS_EQ(EQ) : WR_QLDS_PRE_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t k0 = (blockIdx.x * WR_WAVES_PER_BLOCK + wave) * 4;

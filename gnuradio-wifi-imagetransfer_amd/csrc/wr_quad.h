@@ -135,13 +135,21 @@ __device__ __forceinline__ bool parse_signal(uint32_t bits, int& enc, int& len)
 
 // ---------------------------------------------------------------------------------------------
 // a2 copy + a3: sync_short's first 384 copied samples, LTS correlation, frame start, fine CFO -- for TWO frames at a
-// time ("pair"): their derotated samples sit side by side in LDS and the 2 x 320 x 64 complex correlation runs on the
-// f32 matrix cores (spec rule 6), off the vector ALU that bounds this kernel.
+// time ("pair"): their derotated samples sit side by side in LDS, as float32 and as 8-bit integers.  WHERE the LTS peaks
+// are is searched on the integers -- the 2 x 320 x 64 complex correlation is 15 v_mfma_i32_16x16x64_i8 on the matrix
+// cores --, WHAT they are (the values the fine CFO is taken from) is computed in float32 for the two (rarely eight)
+// candidates of a frame alone (spec rule 6).
 //
-// LDS: frame e (0/1) of the pair at floats [768 e, 768 e + 768): y[m] = (re, im) interleaved, m = 0..383.
+// LDS: frame e (0/1) of the pair at floats [768 e, 768 e + 768): y[m] = (re, im) interleaved, m = 0..383; its 8-bit
+// image at byte 4 * WR_PRE_Q8 + 832 e: 768 bytes (re, im) interleaved + 64 zero bytes (the rows of the last lag blocks
+// run past the samples; their taps are zero there).
 #define WR_PRE_FRAME_FLOATS 768
+#define WR_PRE_Q8           1536                 // float index where the 8-bit images start
+#define WR_PRE_Q8_FRAME     832                  // bytes per frame
+#define WR_QLDS_PRE_FLOATS  (WR_PRE_Q8 + 2 * WR_PRE_Q8_FRAME / 4)      // LDS of the preamble phase, per wave
 
 typedef float wr_f4 __attribute__((ext_vector_type(4)));
+typedef int   wr_i4 __attribute__((ext_vector_type(4)));
 
 // One frame before the correlation: what sync_short found, and whether the LTS search can run.
 struct PreFrame {
@@ -166,6 +174,24 @@ __device__ __forceinline__ void preamble_load(const PreFrame& f, int lane, PreSa
     for (int pass = 0; pass < 6; pass++) ps.xs[pass] = load_sample(f.x, f.t - 16 + (pass * 64 + lane), ns);
 }
 
+__device__ __forceinline__ int wave_max_int(int v)
+{
+    v = row_max16(v);
+    const int m0 = __builtin_amdgcn_readlane(v, 15), m1 = __builtin_amdgcn_readlane(v, 31);
+    const int m2 = __builtin_amdgcn_readlane(v, 47), m3 = __builtin_amdgcn_readlane(v, 63);
+    const int m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
+    return m01 > m23 ? m01 : m23;
+}
+
+// spec rule 6, stage 1: a component scaled into the 8-bit range (NaN -> 0)
+__device__ __forceinline__ int quant8(float x, float scale)
+{
+    const float r = __builtin_rintf(x * scale);
+    const bool in = (r >= -127.0f) && (r <= 127.0f);
+    const float alt = r > 127.0f ? 127.0f : (r < -127.0f ? -127.0f : 0.0f);
+    return (int)(in ? r : alt);
+}
+
 __device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const PreFrame& f1, const PreSamples& s0,
                                                        const PreSamples& s1, float* ylds, int lane)
 {
@@ -174,6 +200,8 @@ __device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const
         const PreFrame& f = e ? f1 : f0;
         const PreSamples& ps = e ? s1 : s0;
         if (!f.search) continue;                            // wave-uniform
+        c32 yv[6];
+        uint32_t mx = 0;
 #pragma unroll
         for (int pass = 0; pass < 6; pass++) {
             const int m = pass * 64 + lane;
@@ -181,112 +209,185 @@ __device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const
             sp_sincos(-f.cfo_c * (float)m, s, c);
             const c32 y = sp_rot(ps.xs[pass], s, c);
             *reinterpret_cast<float2*>(ylds + WR_PRE_FRAME_FLOATS * e + 2 * m) = make_float2(y.re, y.im);
+            yv[pass] = y;
+            const uint32_t br = __float_as_uint(y.re) & 0x7fffffffu, bi = __float_as_uint(y.im) & 0x7fffffffu;
+            mx = br > mx ? br : mx;
+            mx = bi > mx ? bi : mx;
         }
+        // the 8-bit image: a power of two puts the largest component of the frame into [64, 128)
+        const int E = wave_max_int((int)mx) >> 23;           // largest biased exponent (255: an Inf or NaN among the samples)
+        const int sfield = 260 - E > 254 ? 254 : 260 - E;
+        const float scale = __uint_as_float((uint32_t)sfield << 23);
+        uint8_t* q8 = reinterpret_cast<uint8_t*>(ylds + WR_PRE_Q8) + WR_PRE_Q8_FRAME * e;
+#pragma unroll
+        for (int pass = 0; pass < 6; pass++) {
+            const int m = pass * 64 + lane;
+            const int qr = quant8(yv[pass].re, scale), qi = quant8(yv[pass].im, scale);
+            *reinterpret_cast<uint16_t*>(q8 + 2 * m) = (uint16_t)((qr & 0xff) | ((qi & 0xff) << 8));
+        }
+        if (lane < 16) *reinterpret_cast<uint32_t*>(q8 + 768 + 4 * lane) = 0u;
     }
 }
 
-// corr[i] = sum_k conj(lts[k]) y[i + k] for the 320 lags of both frames of the pair, as a GEMM on v_mfma_f32_16x16x4_f32
-// (bit for bit a k-ordered fmaf chain: tools/mfma_f32_probe.hip).  Lags in blocks of 8, i = 8 a + b:
-//   M: 80 rows (frame e, block a) = 5 tiles of 16;   the row of (e, a) is the 144 contiguous floats from sample 8a on;
-//   N: 16 columns = (b, real part) b = 0..7, then (b, imaginary part);      K: 144 = 36 instructions, 4 floats each.
-// Instruction 4 j + s' takes the floats phi = 16 j + 4 kk + s' (kk = lane >> 4 = its k index): one ds_read_b128 per
-// lane, tile and j feeds four instructions; the matching B values come as one 16-byte load from WR_LTS_MFMA_B.
+// Stage 1 of the search: corr_q[i] = sum_k conj(lq[k]) yq[i + k] for the 320 lags of both frames of the pair in exact
+// integer arithmetic, as a GEMM on v_mfma_i32_16x16x64_i8 (operand layout: tools/mfma_i8_probe.hip).  Lags in blocks of
+// 8, i = 8 a + b:
+//   M: 80 rows (frame e, block a) = 5 tiles of 16;   the row of (e, a) is the 144 contiguous bytes from sample 8a on
+//      (read as 192: the taps beyond are zero);
+//   N: 16 columns = (b, real part) b = 0..7, then (b, imaginary part);      K: 192 = 3 instructions of 64.
+// Instruction t takes the bytes phi = 64 t + 16 kk + j (kk = lane >> 4, j = 0..15): one ds_read_b128 per lane, tile
+// and t; the matching B bytes come as one 16-byte load from WR_LTS_MFMA_B8.
 // Row r' = 4 q + rho of a tile (q = lane >> 4 of the result lane, rho = result register) stands for block
 //   a_local = 8 (rho >> 1) + 2 q + (rho & 1),
 // tiles 0, 1 = frame 0 blocks 0..31; tile 2 = frame 0 blocks 32..39 (rho 0, 1) and frame 1 blocks 0..7 (rho 2, 3);
 // tiles 3, 4 = frame 1 blocks 8..39 -- so that result register n of a frame (n = 0..9 in that order) holds, on the
 // lanes with (lane & 8) == 0, the lags 64 (n >> 1) + 8 (n & 1) + lane: a frame's lags split by register, never by lane.
-__device__ __forceinline__ void lts_corr_pair(const float* ylds, int lane, wr_f4 (&acc)[5])
+__device__ __forceinline__ void lts_corr_pair_q8(const float* ylds, int lane, wr_i4 (&acc)[5])
 {
     const int rp = lane & 15, kk = lane >> 4;
     const int al = 8 * ((rp & 3) >> 1) + 2 * (rp >> 2) + (rp & 1);
     const int e2 = (rp & 3) >> 1;                    // tile 2: which frame this row belongs to
-    const float* arow[5];
-    arow[0] = ylds + 16 * al + 4 * kk;
-    arow[1] = ylds + 16 * (16 + al) + 4 * kk;
-    arow[2] = ylds + (e2 ? WR_PRE_FRAME_FLOATS + 16 * (al & 7) : 16 * (32 + (al & 7))) + 4 * kk;
-    arow[3] = ylds + WR_PRE_FRAME_FLOATS + 16 * (8 + al) + 4 * kk;
-    arow[4] = ylds + WR_PRE_FRAME_FLOATS + 16 * (24 + al) + 4 * kk;
-    const float4* __restrict__ bt = reinterpret_cast<const float4*>(WR_LTS_MFMA_B) + lane;
+    const uint8_t* q8 = reinterpret_cast<const uint8_t*>(ylds + WR_PRE_Q8);
+    const uint8_t* arow[5];
+    arow[0] = q8 + 16 * al + 16 * kk;
+    arow[1] = q8 + 16 * (16 + al) + 16 * kk;
+    arow[2] = q8 + (e2 ? WR_PRE_Q8_FRAME + 16 * (al & 7) : 16 * (32 + (al & 7))) + 16 * kk;
+    arow[3] = q8 + WR_PRE_Q8_FRAME + 16 * (8 + al) + 16 * kk;
+    arow[4] = q8 + WR_PRE_Q8_FRAME + 16 * (24 + al) + 16 * kk;
+    const wr_i4* __restrict__ bt = reinterpret_cast<const wr_i4*>(WR_LTS_MFMA_B8) + lane;
 #pragma unroll
-    for (int t = 0; t < 5; t++) acc[t] = wr_f4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int t = 0; t < 5; t++) acc[t] = wr_i4{ 0, 0, 0, 0 };
 #pragma unroll
-    for (int j = 0; j < 9; j++) {
-        const float4 bq = bt[64 * j];
-        float4 aq[5];
+    for (int t3 = 0; t3 < 3; t3++) {
+        const wr_i4 bq = bt[64 * t3];
 #pragma unroll
-        for (int t = 0; t < 5; t++) aq[t] = *reinterpret_cast<const float4*>(arow[t] + 16 * j);
-        const float bs[4] = { bq.x, bq.y, bq.z, bq.w };
-#pragma unroll
-        for (int sp = 0; sp < 4; sp++) {
-#pragma unroll
-            for (int t = 0; t < 5; t++) {
-                const float as = sp == 0 ? aq[t].x : sp == 1 ? aq[t].y : sp == 2 ? aq[t].z : aq[t].w;
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bs[sp], acc[t], 0, 0, 0);
-            }
+        for (int t = 0; t < 5; t++) {
+            const wr_i4 aq = *reinterpret_cast<const wr_i4*>(arow[t] + 64 * t3);
+            acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aq, bq, acc[t], 0, 0, 0);
         }
     }
 }
 
-// Frame start and fine CFO of one frame from its 320 correlation values: cr[n] = result register n of the frame (real
-// parts on the lanes with (lane & 8) == 0, imaginary parts eight lanes further up).  All results wave-uniform.
-// Returns false when no LTS pair was found.
-__device__ __forceinline__ bool lts_peaks(const float (&cr)[10], int lane, int& fs, float& cfo_f)
+// Stage 1 for one frame: the candidate lags.  cq[n] = result register n of the frame (real parts on the lanes with
+// (lane & 8) == 0, imaginary parts eight lanes further up).  The integers are below 2^24, so their float32 images are
+// exact and |corr_q|^2 = fma(im, im, re re) is the same number on the CPU; it is >= +0 and no NaN, so its bit pattern
+// orders like a signed integer; already-taken entries and the lanes that hold imaginary parts are -1.  Per round: one
+// integer max over the wave, then the lowest lag that holds it (per register the first lane of a ballot; lag = base +
+// lane).  The two largest; when they are not exactly 64 lags apart, the eight largest.  Returns their number.
+__device__ __forceinline__ int lts_candidates(const int (&cq)[10], int lane, int (&cand)[8])
 {
-    // The four largest |corr|^2 in turn, lowest lag first among equal values.  |corr|^2 >= +0, so its bit pattern
-    // orders like a signed integer; NaN, already-taken entries and the lanes that hold imaginary parts are -1
-    // ("invalid").  Per round: one integer max over the wave (DPP inside the rows, the four row results through
-    // SGPRs), then the lowest lag that holds it (per register the first lane of a ballot; lag = base + lane).
-    float ci[10];
     int km[10];
     const bool holds_re = (lane & 8) == 0;
 #pragma unroll
     for (int n = 0; n < 10; n++) {
-        ci[n] = dpp_zero<0x108>(cr[n]);                         // row_shl:8: the imaginary part from lane + 8
-        const float mag = fma_(ci[n], ci[n], cr[n] * cr[n]);
-        km[n] = (holds_re && mag >= 0.0f) ? (int)__float_as_uint(mag) : -1;
+        const int ci = __builtin_bit_cast(int, dpp_zero<0x108>(__builtin_bit_cast(float, cq[n])));      // row_shl:8: the imaginary part from lane + 8
+        const float fr = (float)cq[n], fi = (float)ci;
+        const float mag = fma_(fi, fi, fr * fr);
+        km[n] = holds_re ? (int)__float_as_uint(mag) : -1;
     }
-    int top_off[4] = { -1, -1, -1, -1 };
-    c32 top_val[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+    int n_cand = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        // The pair search below takes the first pair that is exactly 64 lags apart and looks no further; the pair
-        // (largest, second largest) comes first.  When those two are 64 apart -- every clean frame -- the third and
-        // fourth largest can never be looked at: their rounds are skipped (wave-uniform; same result by construction).
-        if (r == 2) {
-            const int d01 = top_off[0] > top_off[1] ? top_off[0] - top_off[1] : top_off[1] - top_off[0];
-            if (top_off[0] >= 0 && top_off[1] >= 0 && d01 == 64) break;
+    for (int r = 0; r < 8; r++) {
+        cand[r] = 0;
+        if (r >= 2) {
+            const int d01 = cand[0] > cand[1] ? cand[0] - cand[1] : cand[1] - cand[0];
+            if (d01 == 64) continue;                            // wave-uniform: the usual case, the two LTS peaks
         }
         int m = km[0];
 #pragma unroll
         for (int n = 1; n < 10; n++) m = km[n] > m ? km[n] : m;
-        m = row_max16(m);
-        const int m0 = __builtin_amdgcn_readlane(m, 15), m1 = __builtin_amdgcn_readlane(m, 31);
-        const int m2 = __builtin_amdgcn_readlane(m, 47), m3 = __builtin_amdgcn_readlane(m, 63);
-        const int m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
-        const int best = m01 > m23 ? m01 : m23;
-        int w = -1;
-        c32 val = { 0.0f, 0.0f };
-        if (best >= 0) {
-            w = 0x7fffffff;
+        const int best = wave_max_int(m);
+        int w = 0x7fffffff;
 #pragma unroll
-            for (int n = 0; n < 10; n++) {
-                const uint64_t hit = __ballot(km[n] == best);
-                const int cand = 64 * (n >> 1) + 8 * (n & 1) + (int)__builtin_ctzll(hit | (1ull << 63));
-                if (hit) w = cand < w ? cand : w;
-            }
-            const int wn = ((w >> 6) << 1) | ((w >> 3) & 1), wl = w & 0x37;
+        for (int n = 0; n < 10; n++) {
+            const uint64_t hit = __ballot(km[n] == best);
+            const int lag = 64 * (n >> 1) + 8 * (n & 1) + (int)__builtin_ctzll(hit | (1ull << 63));
+            if (hit) w = lag < w ? lag : w;
+        }
+        const int wn = ((w >> 6) << 1) | ((w >> 3) & 1), wl = w & 0x37;
 #pragma unroll
-            for (int n = 0; n < 10; n++) {
-                if (n == wn) {
-                    val = { bcast(cr[n], wl), bcast(ci[n], wl) };
-                    if (lane == wl) km[n] = -1;
-                }
+        for (int n = 0; n < 10; n++)
+            if (n == wn && lane == wl) km[n] = -1;
+        cand[r] = w;
+        n_cand = r + 1;
+    }
+    return n_cand;
+}
+
+// Stage 2 for the pair: the float32 correlation values of the candidates.  Lane (e, c, part) = (lane >> 4 & 1, lane >> 1 & 7,
+// lane & 1) computes the real (part 0) or imaginary part of corr at candidate c of frame e: lag i = 8a + b reads the 144
+// floats from sample 8a on; ONE fmaf chain over the floats in the order j = 0..8, s' = 0..3, kk = 0..3 of
+// phi = 16 j + 4 kk + s' with the coefficients of WR_LTS_MFMA_B (column b + 8 part; zero outside the 64 taps) -- the chain
+// a v_mfma_f32_16x16x4_f32 form accumulated in the middle of round 2, kept so that the values did not move.
+__device__ __forceinline__ float lts_exact_pair(const float* ylds, int lane, const int (&cand0)[8], const int (&cand1)[8], int& lag)
+{
+    const int e = (lane >> 4) & 1, c = (lane >> 1) & 7, part = lane & 1;
+    lag = e ? cand1[0] : cand0[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) lag = (c == k) ? (e ? cand1[k] : cand0[k]) : lag;
+    const int a = lag >> 3, col = (lag & 7) + 8 * part;
+    const float4* __restrict__ arow = reinterpret_cast<const float4*>(ylds + WR_PRE_FRAME_FLOATS * e + 16 * a);
+    const float4* __restrict__ bt = reinterpret_cast<const float4*>(WR_LTS_MFMA_B) + col;
+    float acc = 0.0f;
+#pragma unroll 1
+    for (int j = 0; j < 9; j++) {            // not unrolled: 32 operand registers per step are enough to keep in flight
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) { av[kk] = arow[4 * j + kk]; bv[kk] = bt[64 * j + 16 * kk]; }
+#pragma unroll
+        for (int sp = 0; sp < 4; sp++) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const float as = sp == 0 ? av[kk].x : sp == 1 ? av[kk].y : sp == 2 ? av[kk].z : av[kk].w;
+                const float bs = sp == 0 ? bv[kk].x : sp == 1 ? bv[kk].y : sp == 2 ? bv[kk].z : bv[kk].w;
+                acc = fma_(as, bs, acc);
             }
         }
-        top_off[r] = w;
-        top_val[r] = val;
     }
+    return acc;
+}
+
+// The (up to) four largest candidates of both frames of the pair by |corr|^2 = fma(im, im, re re) of their float32 values
+// -- lowest lag first among equal values, a NaN is never a peak.  `ex`, `lag` as lts_exact_pair left them: rows 0 and 1 of
+// the wave hold frame 0 and 1, lane 2c the real part of candidate c, lane 2c + 1 the imaginary part.  Per round one
+// integer max over each row (the bit pattern of a magnitude >= +0 orders like a signed integer), then the lowest lag
+// among the lanes that hold it.
+__device__ __forceinline__ void lts_top4_pair(float ex, int lag, int lane, const int (&n_cand)[2], int (&top_off)[2][4], c32 (&top_val)[2][4])
+{
+    const int e = (lane >> 4) & 1, c = (lane >> 1) & 7, part = lane & 1;
+    const float im = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ex), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]: the neighbour
+    const float mag = fma_(im, im, ex * ex);
+    const int nc = e ? n_cand[1] : n_cand[0];
+    int key = (lane < 32 && part == 0 && c < nc && mag >= 0.0f) ? (int)__float_as_uint(mag) : -1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int m = row_max16(key);
+        const int b0 = __builtin_amdgcn_readlane(m, 15), b1 = __builtin_amdgcn_readlane(m, 31);
+        const int best = e ? b1 : b0;
+        const bool hit = lane < 32 && key >= 0 && key == best;
+        const int nl = row_max16(hit ? -lag : (int)0x80000000);                  // lowest lag = largest negated lag
+        const int l0 = -__builtin_amdgcn_readlane(nl, 15), l1 = -__builtin_amdgcn_readlane(nl, 31);
+        const bool win = hit && lag == (e ? l1 : l0);
+        const uint64_t wb = __ballot(win);
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            const uint32_t wf = (uint32_t)(wb >> (16 * f)) & 0xffffu;
+            top_off[f][r] = -1;
+            top_val[f][r] = { 0.0f, 0.0f };
+            if (wf) {                                                           // wave-uniform
+                const int wl = 16 * f + (int)__builtin_ctz(wf);
+                top_off[f][r] = f ? l1 : l0;
+                top_val[f][r] = { bcast(ex, wl), bcast(ex, wl + 1) };
+            }
+        }
+        if (win) key = -1;
+    }
+}
+
+// sync_long's pair search over the (up to) four largest peaks of a frame: frame start and fine CFO.  Returns false when no
+// LTS pair was found.
+__device__ __forceinline__ bool lts_pair_search(const int (&top_off)[4], const c32 (&top_val)[4], int& fs, float& cfo_f)
+{
     int found = 0;
     fs = WIFIRX_SYNC_LENGTH;
     cfo_f = 0.0f;
@@ -336,9 +437,35 @@ __device__ __forceinline__ QuadSeed quad_seed_none()
 __device__ __forceinline__ void preamble_pair_finish(const PreFrame& f0, const PreFrame& f1, int p, const float* lds, int lane, QuadSeed& seed)
 {
     const PreFrame pf[2] = { f0, f1 };
-    wr_f4 acc[5];
-    const bool any = pf[0].search || pf[1].search;         // wave-uniform
-    if (any) lts_corr_pair(lds, lane, acc);
+    const bool run[2] = { pf[0].out >= 0 && pf[0].t >= 0 && pf[0].search, pf[1].out >= 0 && pf[1].t >= 0 && pf[1].search };   // wave-uniform
+    int cand[2][8], n_cand[2] = { 0, 0 };
+    int top_off[2][4] = { { -1, -1, -1, -1 }, { -1, -1, -1, -1 } };
+    c32 top_val[2][4];
+    float ex = 0.0f;
+    if (run[0] || run[1]) {
+        wr_i4 acc[5];
+        lts_corr_pair_q8(lds, lane, acc);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) cand[e][c] = 0;
+            if (!run[e]) continue;
+            int cq[10];
+            if (e == 0) {
+#pragma unroll
+                for (int n = 0; n < 8; n++) cq[n] = acc[n >> 2][n & 3];
+                cq[8] = acc[2][0]; cq[9] = acc[2][1];
+            } else {
+                cq[0] = acc[2][2]; cq[1] = acc[2][3];
+#pragma unroll
+                for (int n = 2; n < 10; n++) cq[n] = acc[3 + ((n - 2) >> 2)][(n - 2) & 3];
+            }
+            n_cand[e] = lts_candidates(cq, lane, cand[e]);
+        }
+        int lag;
+        ex = lts_exact_pair(lds, lane, cand[0], cand[1], lag);
+        lts_top4_pair(ex, lag, lane, n_cand, top_off, top_val);
+    }
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         if (pf[e].out < 0) continue;
@@ -348,17 +475,7 @@ __device__ __forceinline__ void preamble_pair_finish(const PreFrame& f0, const P
         if (pf[e].t >= 0) {
             flags = WIFIRX_F_DETECTED | WIFIRX_F_TRUNCATED;
             if (pf[e].search) {
-                float cr[10];
-                if (e == 0) {
-#pragma unroll
-                    for (int n = 0; n < 8; n++) cr[n] = acc[n >> 2][n & 3];
-                    cr[8] = acc[2][0]; cr[9] = acc[2][1];
-                } else {
-                    cr[0] = acc[2][2]; cr[1] = acc[2][3];
-#pragma unroll
-                    for (int n = 2; n < 10; n++) cr[n] = acc[3 + ((n - 2) >> 2)][(n - 2) & 3];
-                }
-                const bool ok = lts_peaks(cr, lane, fs, cfo_f);
+                const bool ok = lts_pair_search(top_off[e], top_val[e], fs, cfo_f);
                 flags = ok ? (WIFIRX_F_DETECTED | WIFIRX_F_SYNC) : WIFIRX_F_DETECTED;
                 if (!ok) { fs = 0; cfo_f = 0.0f; }
             }

@@ -632,13 +632,67 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     /* -- sync_long SYNC: 64-tap LTS correlation over 320 lags -- */
     c32   corr[WIFIRX_SYNC_LENGTH];
     float mag[WIFIRX_SYNC_LENGTH];
-    for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) {
-        if (spec) {
-            /* Spec rule 6: lag i = 8a + b reads the 144 floats (72 samples, re/im interleaved) from sample 8a on; float
-             * phi = 2m + part meets tap k = m - b (coefficient 0 outside 0..63).  Both sums are ONE fmaf chain each over
-             * the floats in the order j = 0..8, s' = 0..3, kk = 0..3 of phi = 16 j + 4 kk + s' -- the order in which a
-             * chain of 36 4-deep matrix instructions accumulates them.  conj(l) y: real part lr yr + li yi, imaginary part
-             * lr yi - li yr; -li is formed as 0 - li (no negative zero among the coefficients). */
+    int   top[4] = { -1, -1, -1, -1 };
+    if (spec) {
+        /* Spec rule 6.  The search runs in two stages: WHERE the peaks are is decided on 8-bit integers (exact integer
+         * arithmetic: any order of summation gives the same numbers), WHAT they are -- the values the fine CFO is taken
+         * from -- is computed in float32 for the candidates alone.
+         * Stage 1.  The 384 copied samples are scaled by a power of two that puts the largest component into [64, 128)
+         * and rounded to integers in [-127, 127] (NaN -> 0); the taps are rint(64 l) (WR_LTS_Q8).  For every lag the
+         * integer correlation conj(lq) yq, its squared magnitude in float32 (the integers are below 2^24: exact
+         * conversions).  The two largest (lowest lag first among equals) are the candidates; when they are not exactly 64
+         * lags apart, the eight largest are. */
+        int E = 0;                                               /* largest biased exponent among the 768 components */
+        for (int m = 0; m < WIFIRX_SYNC_LENGTH + 64; m++) {
+            uint32_t br, bi;
+            memcpy(&br, &y[m].re, 4); memcpy(&bi, &y[m].im, 4);
+            const int er = (int)((br >> 23) & 0xffu), ei = (int)((bi >> 23) & 0xffu);
+            if (er > E) E = er;
+            if (ei > E) E = ei;
+        }
+        int sfield = 260 - E;                                    /* x < 2^(E-126)  ->  x 2^(133-E) < 128 */
+        if (sfield > 254) sfield = 254;
+        const uint32_t sbits = (uint32_t)sfield << 23;
+        float scale;
+        memcpy(&scale, &sbits, 4);
+        int8_t q[2 * (WIFIRX_SYNC_LENGTH + 64)];
+        for (int m = 0; m < 2 * (WIFIRX_SYNC_LENGTH + 64); m++) {
+            const float v = (&y[0].re)[m] * scale;
+            const float r = rintf(v);
+            q[m] = (int8_t)((r >= -127.0f && r <= 127.0f) ? (int)r : (r > 127.0f ? 127 : (r < -127.0f ? -127 : 0)));
+        }
+        float mag1[WIFIRX_SYNC_LENGTH];
+        for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) {
+            int32_t cr = 0, ci = 0;
+            for (int k = 0; k < 64; k++) {
+                const int lr = WR_LTS_Q8[2 * k], li = WR_LTS_Q8[2 * k + 1];
+                const int yr = q[2 * (i + k)], yi = q[2 * (i + k) + 1];
+                cr += lr * yr + li * yi;
+                ci += lr * yi - li * yr;
+            }
+            const float fr_ = (float)cr, fi_ = (float)ci;
+            mag1[i] = fmaf(fi_, fi_, fr_ * fr_);
+        }
+        int cand[8], n_cand = 0;
+        for (int r = 0; r < 8; r++) {
+            int best = -1;
+            for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) {
+                int used = 0;
+                for (int c = 0; c < n_cand; c++) used |= (cand[c] == i);
+                if (used) continue;
+                if (best < 0 || mag1[i] > mag1[best]) best = i;
+            }
+            cand[n_cand++] = best;
+            if (r == 1 && abs(cand[0] - cand[1]) == 64) break;   /* the usual case: the two LTS peaks */
+        }
+        /* Stage 2.  The candidates' correlation values in float32: lag i = 8a + b reads the 144 floats (72 samples, re/im
+         * interleaved) from sample 8a on; float phi = 2m + part meets tap k = m - b (coefficient 0 outside 0..63).  Both
+         * sums are ONE fmaf chain each over the floats in the order j = 0..8, s' = 0..3, kk = 0..3 of phi = 16 j + 4 kk + s'
+         * (the order in which round 2's matrix-instruction form accumulated them; kept so that the values did not move
+         * when the search went to integers).  conj(l) y: real part lr yr + li yi, imaginary part lr yi - li yr; -li is
+         * formed as 0 - li (no negative zero among the coefficients). */
+        for (int c = 0; c < n_cand; c++) {
+            const int i = cand[c];
             const float* A = &y[8 * (i >> 3)].re;
             const int b = i & 7;
             float ar = 0.0f, ai = 0.0f;
@@ -657,7 +711,21 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                     }
             corr[i].re = ar; corr[i].im = ai;
             mag[i] = fmaf(ai, ai, ar * ar);
-        } else {
+        }
+        /* the (up to) four largest candidates by their float32 magnitude, ties -> lower lag; a NaN magnitude is never a peak */
+        for (int r = 0; r < 4; r++) {
+            int best = -1;
+            for (int c = 0; c < n_cand; c++) {
+                const int i = cand[c];
+                int used = 0;
+                for (int qq = 0; qq < r; qq++) used |= (top[qq] == i);
+                if (used || !(mag[i] >= 0.0f)) continue;
+                if (best < 0 || mag[i] > mag[best] || (mag[i] == mag[best] && i < best)) best = i;
+            }
+            top[r] = best;
+        }
+    } else {
+        for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) {
             double ar = 0, ai = 0;
             for (int k = 0; k < 64; k++) {
                 double lr = WR_LTS_TIME[2 * k], li = WR_LTS_TIME[2 * k + 1];
@@ -667,18 +735,17 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             corr[i].re = (float)ar; corr[i].im = (float)ai;
             mag[i] = hypotf(corr[i].re, corr[i].im);
         }
-    }
-    /* top 4 by magnitude, ties -> lower offset first (stable sort of the upstream list) */
-    int top[4];
-    for (int r = 0; r < 4; r++) {
-        int best = -1;
-        for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) {
-            int used = 0;
-            for (int q = 0; q < r; q++) used |= (top[q] == i);
-            if (used || !(mag[i] >= 0.0f)) continue;            /* a NaN magnitude is never a peak */
-            if (best < 0 || mag[i] > mag[best]) best = i;
+        /* top 4 by magnitude, ties -> lower offset first (stable sort of the upstream list) */
+        for (int r = 0; r < 4; r++) {
+            int best = -1;
+            for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) {
+                int used = 0;
+                for (int q = 0; q < r; q++) used |= (top[q] == i);
+                if (used || !(mag[i] >= 0.0f)) continue;            /* a NaN magnitude is never a peak */
+                if (best < 0 || mag[i] > mag[best]) best = i;
+            }
+            top[r] = best;
         }
-        top[r] = best;
     }
     int   fs = WIFIRX_SYNC_LENGTH, found = 0;
     float cfo_f = 0.0f;

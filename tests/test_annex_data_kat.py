@@ -183,3 +183,47 @@ def test_lts_correlation_operand_table_matches_the_lts():
         L[k % 64] = v
     ref = np.fft.ifft(L) * 64 / math.sqrt(52)
     assert np.abs(lts[:, 0] + 1j * lts[:, 1] - ref).max() < 1e-7
+
+
+def _int_table(name):
+    txt = open(os.path.join(ROOT, "include", "wifirx_tables.h")).read()
+    m = re.search(r"%s\[\d+\] = \{(.*?)\};" % name, txt, re.S)
+    return np.array([int(v.strip().rstrip("u"), 0) for v in m.group(1).replace("\n", " ").split(",") if v.strip()], dtype=np.int64)
+
+
+def test_integer_lts_tables_match_the_lts():
+    """spec rule 6, stage 1: WR_LTS_Q8 = rint(64 l), and WR_LTS_MFMA_B8 (kernels only) against it through the layout of
+    v_mfma_i32_16x16x64_i8 written out independently of tools/gen_tables.py: byte j of entry [t][lane] multiplies byte
+    phi = 64 t + 16 (lane >> 4) + j of a row, k = (phi >> 1) - (col & 7), zero outside the 64 taps"""
+    lts = _table("WR_LTS_TIME")
+    q8 = _int_table("WR_LTS_Q8")
+    assert np.array_equal(q8, np.rint(64.0 * lts).astype(np.int64)) and np.abs(q8).max() <= 127
+    words = _int_table("WR_LTS_MFMA_B8").reshape(3, 64, 4)
+    for t in range(3):
+        for lane in range(64):
+            by = np.array([(int(words[t, lane, j >> 2]) >> (8 * (j & 3))) & 0xff for j in range(16)], dtype=np.uint8).view(np.int8)
+            for j in range(16):
+                phi = 64 * t + 16 * (lane >> 4) + j
+                m, part, col = phi // 2, phi % 2, lane & 15
+                k = m - (col & 7)
+                want = 0
+                if 0 <= k < 64:
+                    qr, qi = q8[2 * k], q8[2 * k + 1]
+                    want = (qi if part else qr) if col < 8 else (qr if part else -qi)
+                assert by[j] == want, (t, lane, j)
+
+
+def test_integer_lts_search_finds_the_peaks_of_the_float_search(orc):
+    """the two-stage search (rule 6) against the exhaustive float search of the upstream-literal mode: same frame start
+    and flags on frames from clean to barely detectable, flat and multipath"""
+    from wifirx import txgen
+    rng = np.random.default_rng(3)
+    taps = (rng.standard_normal((64, 6)) + 1j * rng.standard_normal((64, 6))) * np.exp(-0.6 * np.arange(6))
+    taps /= np.sqrt((np.abs(taps) ** 2).sum(axis=1, keepdims=True))
+    for snr, tp in ((30.0, None), (8.0, None), (3.0, None), (18.0, taps), (9.0, taps)):
+        tx = txgen.encode_psdus(txgen.make_psdus(64, 60, seed=int(snr)), 0)
+        iq = txgen.impair(tx.samples, snr, cfo=rng.uniform(-0.03, 0.03, 64), lead=200, total=2048, seed=int(snr) + 9, taps=tp)
+        a = orc.demod_batch(iq.reshape(-1), 2048, orc.make_params(max_sym=tx.n_sym, math_mode=orc.MATH_SPEC))["frames"]
+        b = orc.demod_batch(iq.reshape(-1), 2048, orc.make_params(max_sym=tx.n_sym, math_mode=orc.MATH_LIBM))["frames"]
+        assert np.array_equal(a["frame_start"], b["frame_start"]) and np.array_equal(a["flags"], b["flags"])
+        assert ((a["flags"] & orc.F_SYNC) != 0).mean() > (0.9 if snr > 5 else 0.3)
