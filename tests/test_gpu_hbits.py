@@ -152,3 +152,27 @@ def test_misaligned_planes_pointer_is_refused(capi):
     iq.free()
     rx.free_out(dev)
     rx.close()
+
+
+def test_mid_size_batch_partial_decode_waves(capi):
+    """90 000 frames: the throughput decoder cuts them into tasks of 88 frames (64 lanes with two frames... 24 of them,
+    40 with one) -- planes from the demod kernel, every PSDU back, the last task ragged"""
+    from wifirx import txgen
+    n, n_t = 90001, 64
+    psdu = txgen.make_psdus(n_t, 150, seed=78)
+    tx = txgen.encode_psdus(psdu, 4)
+    slot = 2048
+    assert 160 + tx.samples.shape[1] <= slot
+    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=0)
+    slots = rx.alloc(n * slot * 8)
+    rx.synth_slots(tx.samples, slots.ptr, slot, n, 160, 26.0, 0.037, 5)
+    dev = rx.alloc_out(n, psdu_stride=160, want_hbits=True, want_idx=False)
+    rx.demod_batch_dev(slots.ptr, slot, n, dev)
+    rx.decode_batch_dev(n, dev)
+    rx.sync()
+    r = rx.download_out(dev, n)
+    ok = (r["frames"]["flags"] & capi.F_CRC_OK) != 0
+    assert ok.mean() > 0.999
+    assert np.array_equal(r["psdu"][ok][:, :150], psdu[np.arange(n) % n_t][ok])
+    assert ok[-1] and ok[-88:].all()
+    rx.free_out(dev); slots.free(); rx.close()
