@@ -581,10 +581,20 @@ __device__ __forceinline__ void plane_words(const c32 (&Y)[4], uint32_t& w0, uin
 {
     const uint64_t m0 = __ballot(decide_bit<NB, B>(Y[0])), m1 = __ballot(decide_bit<NB, B>(Y[1]));
     const uint64_t m2 = __ballot(decide_bit<NB, B>(Y[2])), m3 = __ballot(decide_bit<NB, B>(Y[3]));
+    // frames 0, 1 sit in the low words of the masks, 2, 3 in the high words; s_pack_{ll,hh} puts a frame's two halves together
+    const uint32_t a0 = (uint32_t)m0, a1 = (uint32_t)m1, a2 = (uint32_t)m2, a3 = (uint32_t)m3;
+    const uint32_t b0 = (uint32_t)(m0 >> 32), b1 = (uint32_t)(m1 >> 32), b2 = (uint32_t)(m2 >> 32), b3 = (uint32_t)(m3 >> 32);
 #pragma unroll
     for (int f = 0; f < 4; f++) {
-        const uint32_t lo = (uint32_t)((m0 >> (16 * f)) & 0xffffu) | ((uint32_t)((m1 >> (16 * f)) & 0xffffu) << 16);
-        const uint32_t hi = (uint32_t)((m2 >> (16 * f)) & 0xffffu) | ((uint32_t)((m3 >> (16 * f)) & 0xffffu) << 16);
+        const uint32_t p0 = f < 2 ? a0 : b0, p1 = f < 2 ? a1 : b1, p2 = f < 2 ? a2 : b2, p3 = f < 2 ? a3 : b3;
+        uint32_t lo, hi;
+        if (f & 1) {
+            asm("s_pack_hh_b32_b16 %0, %1, %2" : "=s"(lo) : "s"(p0), "s"(p1));
+            asm("s_pack_hh_b32_b16 %0, %1, %2" : "=s"(hi) : "s"(p2), "s"(p3));
+        } else {
+            asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(lo) : "s"(p0), "s"(p1));
+            asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(hi) : "s"(p2), "s"(p3));
+        }
         asm("v_writelane_b32 %0, %1, %2" : "+v"(w0) : "s"(lo & WR_HB_DATA_LO), "n"(16 * f));
         asm("v_writelane_b32 %0, %1, %2" : "+v"(w1) : "s"(hi & WR_HB_DATA_HI), "n"(16 * f));
     }
