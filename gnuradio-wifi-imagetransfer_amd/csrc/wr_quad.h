@@ -783,6 +783,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     float*   llr = llr_all ? llr_all + (size_t)out_base * per * prm.llr_bits : nullptr;
     float2*  car = car_all ? car_all + (size_t)out_base * per : nullptr;
 
+    int pk = 0;                                                // (s - 2) mod 127: index into the pilot polarity sequence
+    float t4 = WR_T4_64F[0];                                   // float32 (2 pi s 80) / 64 of the current symbol
     for (int s = 0;; s++) {
         const int off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
         bool act = alive && (s <= n_sym + 2);
@@ -862,7 +864,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         {
             // upstream: 2 pi s 80 (eps0 + d_er) / 64 in double; spec: the factor that depends on s alone comes from a
             // float32 table, eps0 and d_er are float32
-            const float kf = WR_T4_64F[s] * (eps0 + d_er);
+            const float kf = t4 * (eps0 + d_er);
+            t4 = WR_T4_64F[s < 518 ? s + 1 : 519];              // the next symbol's factor: requested a whole iteration early
             // b = phasor of bin r + 16; lane 0 of the row holds exp(-j kf 16), whose conjugate is the step
             c32 b;
             sp_sincos_small(kf * (float)(r - 16), b.im, b.re);
@@ -875,32 +878,28 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         }
         // (2) pilots: bins 11, 25, 39, 53 = (lane 11, j 0), (lane 9, j 1), (lane 7, j 2), (lane 5, j 3)
         c32 X11 = row_bcast<11>(X[0]), X25 = row_bcast<9>(X[1]), X39 = row_bcast<7>(X[2]), X53 = row_bcast<5>(X[3]);
-        // polarity of symbol s - 2 as a sign-bit mask (wave-uniform: scalar registers): negating = xor
+        // polarity of symbol s - 2 as a sign-bit mask (wave-uniform: scalar registers): negating = xor; pilot sum S,
+        // (3) the pilots with the polarity removed and the residual offset estimate -- one branch on the kind of symbol
         uint32_t sgn = 0;
+        c32 S, cur0, cur1, cur2, cur3;
+        float er = 0.0f;
         if (s >= 2) {
-            const int pk = (s - 2) % 127;
             const uint64_t bits = pk < 64 ? (WR_POLARITY_NEG_LO >> pk) : (WR_POLARITY_NEG_HI >> (pk - 64));
             sgn = (uint32_t)(bits & 1ull) << 31;
-        }
-        c32 S;
-        if (s < 2) S = cadd(cadd(csub(X11, X25), X39), X53);
-        else       S = cflip(csub(cadd(cadd(X11, X39), X25), X53), sgn);
-        // (3) residual offset estimate
-        c32 cur0, cur1, cur2, cur3;
-        if (s < 2) { cur0 = X11; cur1 = cneg(X25); cur2 = X39; cur3 = X53; }
-        else {
+            S = cflip(csub(cadd(cadd(X11, X39), X25), X53), sgn);
             cur0 = cflip(X11, sgn);
             cur1 = cflip(X25, sgn);
             cur2 = cflip(X39, sgn);
             cur3 = cflip(X53, sgn ^ 0x80000000u);
-        }
-        float er = 0.0f;
-        if (s >= 2) {
             const float2 q0 = pvl[0], q1 = pvl[1], q2 = pvl[2], q3 = pvl[3];
             const c32 prev0 = { q0.x, q0.y }, prev1 = { q1.x, q1.y }, prev2 = { q2.x, q2.y }, prev3 = { q3.x, q3.y };
             c32 acc = cadd(cadd(cadd(sp_conj_mul(prev0, cur0), sp_conj_mul(prev1, cur1)),
                                 sp_conj_mul(prev2, cur2)), sp_conj_mul(prev3, cur3));
             er = sp_atan2(acc.im, acc.re) * er_scale;
+            pk = pk == 126 ? 0 : pk + 1;                       // (s - 2) mod 127 of the next symbol
+        } else {
+            S = cadd(cadd(csub(X11, X25), X39), X53);
+            cur0 = X11; cur1 = cneg(X25); cur2 = X39; cur3 = X53;
         }
         __builtin_amdgcn_wave_barrier();
         if (r == 0) {
