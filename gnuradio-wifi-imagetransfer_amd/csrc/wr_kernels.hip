@@ -1,11 +1,12 @@
 // wr_kernels.hip -- HIP kernels of the wifirx receive chain for gfx950 (MI355X, CDNA4).
 //
-// One wavefront (64 lanes) owns one frame: lane <-> sample while scanning for the short preamble
-// and correlating against the long training symbol, lane <-> sub-carrier from the FFT on.  The
-// per-frame state of the reference's frame_equalizer (d_er, previous pilots, channel estimate H)
-// lives in registers for the whole frame, so the symbols of a frame are walked in order by the
-// same wave and thousands of frames run side by side.  The whole chain is fused: the samples of
-// a slot are read from HBM once, the only HBM writes are the decisions / LLRs / frame record.
+// One wavefront (64 lanes) owns four frames.  Preamble phase: the whole wave works on one slot (lane <-> sample while
+// scanning for the short preamble) or on a pair of frames (the LTS search on the int8 matrix cores, wr_quad.h); symbol
+// phase: row f = lanes 16f..16f+15 owns frame f, lane r of the row holds bins r + 16 j.  The per-frame state of the
+// reference's frame_equalizer (d_er, previous pilots, channel estimate H) lives in registers and wave-private LDS for
+// the whole frame, so the symbols of a frame are walked in order by the same wave and a million frames run side by
+// side.  The whole chain is fused: the samples of a slot are read from HBM once, the only HBM writes are the
+// decisions / LLRs / frame record (and, on request, the decisions as bit planes for decode_mac).
 //
 // Replaces, per the reference's flowgraph (gnu_radio/IRS_AP.py:268-285,294-311):
 //   a1  delay(16), conjugate_cc, multiply_vcc, moving_average_cc(48), complex_to_mag_squared,

@@ -148,7 +148,6 @@ __device__ __forceinline__ bool parse_signal(uint32_t bits, int& enc, int& len)
 #define WR_PRE_Q8_FRAME     832                  // bytes per frame
 #define WR_QLDS_PRE_FLOATS  (WR_PRE_Q8 + 2 * WR_PRE_Q8_FRAME / 4)      // LDS of the preamble phase, per wave
 
-typedef float wr_f4 __attribute__((ext_vector_type(4)));
 typedef int   wr_i4 __attribute__((ext_vector_type(4)));
 
 // One frame before the correlation: what sync_short found, and whether the LTS search can run.
