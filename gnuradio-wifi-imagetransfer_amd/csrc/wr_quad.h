@@ -182,13 +182,15 @@ __device__ __forceinline__ int wave_max_int(int v)
     return m01 > m23 ? m01 : m23;
 }
 
-// spec rule 6, stage 1: a component scaled into the 8-bit range (NaN -> 0)
+// spec rule 6, stage 1: a component scaled into the 8-bit range, rounded to nearest even and clamped to [-127, 127]; NaN -> 0.
+// v_cvt_i32_f32 saturates and turns a NaN into 0 (the integer clamp then does the rest), which is the rule's wording.
 __device__ __forceinline__ int quant8(float x, float scale)
 {
     const float r = __builtin_rintf(x * scale);
-    const bool in = (r >= -127.0f) && (r <= 127.0f);
-    const float alt = r > 127.0f ? 127.0f : (r < -127.0f ? -127.0f : 0.0f);
-    return (int)(in ? r : alt);
+    int q;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(q) : "v"(r));
+    q = q > 127 ? 127 : q;
+    return q < -127 ? -127 : q;
 }
 
 __device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const PreFrame& f1, const PreSamples& s0,
@@ -201,12 +203,16 @@ __device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const
         if (!f.search) continue;                            // wave-uniform
         c32 yv[6];
         uint32_t mx = 0;
+        // spec rule 5a: the phasor of sample m = 64 p + l is that of sample l (exact: sp_sincos of the float angle) carried
+        // p times by exp(-j float(cfo_c 64)) -- two sincos per lane and frame instead of six
+        c32 wl, w64;
+        sp_sincos(-f.cfo_c * (float)lane, wl.im, wl.re);
+        sp_sincos(-f.cfo_c * 64.0f, w64.im, w64.re);
 #pragma unroll
         for (int pass = 0; pass < 6; pass++) {
             const int m = pass * 64 + lane;
-            float s, c;
-            sp_sincos(-f.cfo_c * (float)m, s, c);
-            const c32 y = sp_rot(ps.xs[pass], s, c);
+            if (pass) wl = sp_cmul(wl, w64);
+            const c32 y = sp_cmul(ps.xs[pass], wl);
             *reinterpret_cast<float2*>(ylds + WR_PRE_FRAME_FLOATS * e + 2 * m) = make_float2(y.re, y.im);
             yv[pass] = y;
             const uint32_t br = __float_as_uint(y.re) & 0x7fffffffu, bi = __float_as_uint(y.im) & 0x7fffffffu;

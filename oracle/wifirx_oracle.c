@@ -621,13 +621,27 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
     /* -- sync_short COPY: coarse derotation of the first 383 samples (a 384th is formed too: the spec's correlation
      *    multiplies it by zero coefficients, DESIGN.md section 4 rule 6) -- */
     c32 y[WIFIRX_SYNC_LENGTH + 64];
-    for (int m = 0; m < WIFIRX_SYNC_LENGTH + 64; m++) {
-        c32 xs = x_at(x, n_samp, t - 16 + m);
-        float ang = -cfo_c * (float)m;
-        float s, c;
-        if (spec) sp_sincos(ang, &s, &c); else sincosf(ang, &s, &c);
-        if (spec) y[m] = sp_rot(xs, s, c);
-        else { float complex v = (xs.re + I * xs.im) * (c + I * s); y[m].re = crealf(v); y[m].im = cimagf(v); }
+    if (spec) {
+        /* Spec rule 5a: the phasor of sample m = 64 p + l is that of sample l (sp_sincos of the float angle -cfo_c l)
+         * carried p times by exp(-j float(cfo_c 64)): rule-2 products, two sincos per residue l instead of six. */
+        c32 w64;
+        sp_sincos(-cfo_c * 64.0f, &w64.im, &w64.re);
+        for (int l = 0; l < 64; l++) {
+            c32 w;
+            sp_sincos(-cfo_c * (float)l, &w.im, &w.re);
+            for (int p = 0; p < (WIFIRX_SYNC_LENGTH + 64) / 64; p++) {
+                if (p) w = sp_cmul(w, w64);
+                y[64 * p + l] = sp_cmul(x_at(x, n_samp, t - 16 + 64 * p + l), w);
+            }
+        }
+    } else {
+        for (int m = 0; m < WIFIRX_SYNC_LENGTH + 64; m++) {
+            c32 xs = x_at(x, n_samp, t - 16 + m);
+            float ang = -cfo_c * (float)m;
+            float s, c;
+            sincosf(ang, &s, &c);
+            float complex v = (xs.re + I * xs.im) * (c + I * s); y[m].re = crealf(v); y[m].im = cimagf(v);
+        }
     }
     /* -- sync_long SYNC: 64-tap LTS correlation over 320 lags -- */
     c32   corr[WIFIRX_SYNC_LENGTH];
