@@ -149,6 +149,7 @@ __device__ __forceinline__ bool parse_signal(uint32_t bits, int& enc, int& len)
 #define WR_QLDS_PRE_FLOATS  (WR_PRE_Q8 + 2 * WR_PRE_Q8_FRAME / 4)      // LDS of the preamble phase, per wave
 
 typedef int   wr_i4 __attribute__((ext_vector_type(4)));
+typedef float wr_f4 __attribute__((ext_vector_type(4)));
 
 // One frame before the correlation: what sync_short found, and whether the LTS search can run.
 struct PreFrame {
@@ -319,12 +320,53 @@ __device__ __forceinline__ int lts_candidates(const int (&cq)[10], int lane, int
     return n_cand;
 }
 
-// Stage 2 for the pair: the float32 correlation values of the candidates.  Lane (e, c, part) = (lane >> 4 & 1, lane >> 1 & 7,
-// lane & 1) computes the real (part 0) or imaginary part of corr at candidate c of frame e: lag i = 8a + b reads the 144
-// floats from sample 8a on; ONE fmaf chain over the floats in the order j = 0..8, s' = 0..3, kk = 0..3 of
-// phi = 16 j + 4 kk + s' with the coefficients of WR_LTS_MFMA_B (column b + 8 part; zero outside the 64 taps) -- the chain
-// a v_mfma_f32_16x16x4_f32 form accumulated in the middle of round 2, kept so that the values did not move.
+// Stage 2 for the pair: the float32 correlation values of the candidates, on ONE tile of v_mfma_f32_16x16x4_f32: row
+// r' = 8 e + c of the tile is the lag block of candidate c of frame e (lag i = 8a + b reads the 144 floats from sample 8a
+// on), the 16 columns are (b', real part) b' = 0..7 and (b', imaginary part) with the coefficients of WR_LTS_MFMA_B, and
+// 36 instructions sum the floats in the order j = 0..8, s' = 0..3, kk = 0..3 of phi = 16 j + 4 kk + s' -- a k-ascending
+// fmaf chain per output (tools/mfma_f32_probe.hip), the chain the rule writes down.  Of the 16 x 16 outputs the two of each
+// candidate (column b and b + 8 of its row) are fetched into lane (e, c, part) = (lane >> 4 & 1, lane >> 1 & 7, lane & 1);
+// `lag` = that lane's candidate.
 __device__ __forceinline__ float lts_exact_pair(const float* ylds, int lane, const int (&cand0)[8], const int (&cand1)[8], int& lag)
+{
+    // as a row of the tile: lane & 15 = 8 e + c, lane >> 4 = kk
+    const int re_ = (lane >> 3) & 1, rc = lane & 7, kk = lane >> 4;
+    int rlag = re_ ? cand1[0] : cand0[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) rlag = (rc == k) ? (re_ ? cand1[k] : cand0[k]) : rlag;
+    const float* arow = ylds + WR_PRE_FRAME_FLOATS * re_ + 16 * (rlag >> 3) + 4 * kk;
+    const float4* __restrict__ bt = reinterpret_cast<const float4*>(WR_LTS_MFMA_B) + lane;
+    wr_f4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const float4 bq = bt[64 * j];
+        const float4 aq = *reinterpret_cast<const float4*>(arow + 16 * j);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq.w, acc, 0, 0, 0);
+    }
+    // as the holder of one value: lane = 16 e + 2 c + part wants row r' = 8 e + c, column (lag & 7) + 8 part, i.e. result
+    // register r' & 3 of lane 16 (r' >> 2) + column
+    const int e = (lane >> 4) & 1, c = (lane >> 1) & 7, part = lane & 1;
+    lag = e ? cand1[0] : cand0[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) lag = (c == k) ? (e ? cand1[k] : cand0[k]) : lag;
+    const int rr = 8 * e + c;
+    const int src = 4 * (16 * (rr >> 2) + (lag & 7) + 8 * part);
+    // (copies first: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
+    const float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+    const int v0 = __builtin_amdgcn_ds_bpermute(src, __float_as_int(a0));
+    const int v1 = __builtin_amdgcn_ds_bpermute(src, __float_as_int(a1));
+    const int v2 = __builtin_amdgcn_ds_bpermute(src, __float_as_int(a2));
+    const int v3 = __builtin_amdgcn_ds_bpermute(src, __float_as_int(a3));
+    const int sel = (rr & 3) == 0 ? v0 : (rr & 3) == 1 ? v1 : (rr & 3) == 2 ? v2 : v3;
+    return __builtin_bit_cast(float, sel);
+}
+
+#ifdef WR_DEBUG_EXACT
+// the same values as one plain fmaf chain per lane (what the tile replaced): tools/lts_exact_probe.hip compares the two
+__device__ __forceinline__ float lts_exact_pair_valu(const float* ylds, int lane, const int (&cand0)[8], const int (&cand1)[8], int& lag)
 {
     const int e = (lane >> 4) & 1, c = (lane >> 1) & 7, part = lane & 1;
     lag = e ? cand1[0] : cand0[0];
@@ -352,6 +394,7 @@ __device__ __forceinline__ float lts_exact_pair(const float* ylds, int lane, con
     return acc;
 }
 
+#endif
 // The (up to) four largest candidates of both frames of the pair by |corr|^2 = fma(im, im, re re) of their float32 values
 // -- lowest lag first among equal values, a NaN is never a peak.  `ex`, `lag` as lts_exact_pair left them: rows 0 and 1 of
 // the wave hold frame 0 and 1, lane 2c the real part of candidate c, lane 2c + 1 the imaginary part.  Per round one
