@@ -39,11 +39,13 @@ def main():
         # the contract's outputs (idx, LLRs, records) first; then the same kernel also writing the bit planes decode_mac reads
         planes = dev.pop("hbits")
         dev["hbits"] = None
-        rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=1)
-        ms = rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=5)
+        # every figure of this script: the best of three means of three launches, after two warm-up launches (the first
+        # case of a process otherwise carries the clock ramp: 7.65 vs 7.28 ms on the same box)
+        rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=2)
+        ms = min(rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=3) for _ in range(3))
         dev["hbits"] = planes
         rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=1)
-        ms_planes = rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=3)
+        ms_planes = min(rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=3) for _ in range(3))
         rx.decode_batch_dev(n_frames, dev); rx.sync()
         t = time.perf_counter()
         rx.decode_batch_dev(n_frames, dev); rx.sync()
@@ -69,8 +71,8 @@ def main():
         slots = rx.alloc(n_frames * slot_len * 8)
         dev = rx.alloc_out(n_frames, psdu_stride=320, want_hbits=True)
         rx.synth_slots(tmpl, slots.ptr, slot_len, n_frames, 160, 25.0, 0.037, 77)
-        rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=1)
-        ms = rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=5)
+        rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=2)
+        ms = min(rx.time_demod(slots.ptr, slot_len, n_frames, dev, iters=3) for _ in range(3))
         rx.decode_batch_dev(n_frames, dev); rx.sync()
         t = time.perf_counter()
         rx.decode_batch_dev(n_frames, dev); rx.sync()
