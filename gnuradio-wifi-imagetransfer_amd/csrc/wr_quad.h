@@ -732,12 +732,20 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     // get an empty range on a harmless pointer.  32-bit indices: L <= 43200 + 320.
     const bool  has = seed.out >= 0 && seed.x != nullptr && seed.t >= 0;
     const long  t16 = seed.t - 16;
-    const float2* xb = has ? seed.x + t16 : reinterpret_cast<const float2*>(frames);
+    // rows without a frame point at the samples of the wave's first frame: whatever they load is finite and never used
+    const uint64_t has_m = __ballot(has);
+    const int has_l = has_m ? (int)__builtin_ctzll(has_m) : 0;
+    const uint64_t xv = has ? reinterpret_cast<uint64_t>(seed.x + t16) : 0ull;
+    const uint64_t xf = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(xv >> 32), has_l) << 32) |
+                        (uint32_t)__builtin_amdgcn_readlane((int)xv, has_l);
+    const float2* xb = has ? seed.x + t16 : reinterpret_cast<const float2*>(xf);
     const int   m_lo = has ? (int)(t16 < 0 ? -t16 : 0) : 0;
     const long  m_hi_l = seed.n_samp - t16;
     const int   m_hi = has ? (int)(m_hi_l > 0x7fffff00l ? 0x7fffff00l : m_hi_l) : 0;
     const int   L = (int)seed.L;
-    const bool  lo_zero = __all(m_lo == 0 && L <= m_hi);      // wave-uniform: no row starts before its stream does
+    // wave-uniform: no row starts before its stream does, and the first 64 copied samples of every frame exist (what a
+    // row without a symbol reads in the fast path below)
+    const bool  lo_zero = __all(m_lo == 0 && L <= m_hi && (!has || m_hi >= 64));
     const int   out = (int)seed.out;
     const int   trig = (int)seed.t;
     const float cfo_c = seed.cfo_c, cfo_f = seed.cfo_f;
@@ -847,14 +855,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         c32 v[4], cur[4];
         {
             if (lo_zero) {              // act => off0 + 63 < L <= m_hi: every sample of the symbol is in range
-                float2 t[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
-                if (act) {
-                    const float2* p = xb + (off0 + r);
+                // rows without a symbol read the first 64 samples of their (or the wave's first) frame instead: finite
+                // numbers that no output sees -- cheaper than zeroing eight registers per symbol for them
+                const float2* p = xb + ((act ? off0 : 0) + r);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) t[j] = p[16 * j];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) cur[j] = { t[j].x, t[j].y };
+                for (int j = 0; j < 4; j++) { const float2 t = p[16 * j]; cur[j] = { t.x, t.y }; }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
@@ -1141,16 +1146,14 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 int out_l = out;                                  // the row's plane words are addressed from the record index
                 asm volatile("" : "+v"(out_l));                   // every symbol anew: no loop-invariant pointer in registers
                 const int nbu = __builtin_amdgcn_readfirstlane(n_bpsc);      // the loop ran: some lane is active, but
-                const bool uniform = __all(!act || n_bpsc == nbu) && __builtin_amdgcn_readfirstlane((int)act);
-                float wq[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+                const uint64_t act_m = __ballot(act);
+                const bool uniform = (act_m & ~__ballot(n_bpsc == nbu)) == 0 && (act_m & 1ull);
+                const float w1[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
                 const bool csi = prm.llr_csi != 0 && llr_all != nullptr;     // wave-uniform
-                if (csi) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) wq[j] = Wl[64 * j];
-                }
 #define WR_STORE(NB, OK)                                                                                        \
-                { if (csi) store_bins<NB, true>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq, row_o, row_l);  \
-                  else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq, row_o, row_l); \
+                { if (csi) { const float wq[4] = { Wl[0], Wl[64], Wl[128], Wl[192] };                                   \
+                             store_bins<NB, true>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq, row_o, row_l); }  \
+                  else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, w1, row_o, row_l); \
                   if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
                             store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
                 if (uniform) {
