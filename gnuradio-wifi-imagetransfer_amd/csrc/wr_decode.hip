@@ -330,16 +330,19 @@ __device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, in
 // flight together.  One wait state between the write of M0 and the LDS instruction that reads it.
 __device__ __forceinline__ void lds_rows6(const uint32_t (&a)[6], uint32_t (&w)[6])
 {
-    asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\tds_read_addtid_b32 %0\n\t"
-                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tds_read_addtid_b32 %1\n\t"
-                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tds_read_addtid_b32 %2\n\t"
-                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tds_read_addtid_b32 %3\n\t"
-                 "s_mov_b32 m0, %10\n\ts_nop 0\n\tds_read_addtid_b32 %4\n\t"
-                 "s_mov_b32 m0, %11\n\ts_nop 0\n\tds_read_addtid_b32 %5\n\t"
+    uint32_t m0_kept;                    // M0 is the compiler's: handed back as it was found
+    asm volatile("s_mov_b32 %6, m0\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tds_read_addtid_b32 %0\n\t"
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tds_read_addtid_b32 %1\n\t"
+                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tds_read_addtid_b32 %2\n\t"
+                 "s_mov_b32 m0, %10\n\ts_nop 0\n\tds_read_addtid_b32 %3\n\t"
+                 "s_mov_b32 m0, %11\n\ts_nop 0\n\tds_read_addtid_b32 %4\n\t"
+                 "s_mov_b32 m0, %12\n\ts_nop 0\n\tds_read_addtid_b32 %5\n\t"
+                 "s_mov_b32 m0, %6\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&s"(m0_kept)
                  : "s"(a[0]), "s"(a[1]), "s"(a[2]), "s"(a[3]), "s"(a[4]), "s"(a[5])
-                 : "m0", "memory");
+                 : "memory");
 }
 
 // MIXED = false: the tasks whose frames all share one rate (the usual case: where a coded bit sits is then the same
