@@ -69,48 +69,65 @@ __device__ __forceinline__ uint8_t decide(c32 y, int n_bpsc)
     return (uint8_t)r;
 }
 
-// Viterbi over the 24 SIGNAL bits, lane <-> state.  cbits: the 48 de-interleaved hard decisions
-// (bit j = coded bit j).  Returns the 24 decoded bits (bit t = decoded bit t), wave-uniform.
-// The 24 survivor words go through `scr` (24 x 8 B of wave-private LDS): held in SGPRs they would push
-// the kernel's constants out of the scalar register file for the whole symbol loop.
-__device__ __forceinline__ uint32_t viterbi_signal(uint64_t cbits, int lane, uint64_t* scr)
+// Viterbi over the 24 SIGNAL bits of the FOUR frames of a wave at once, lane <-> state.  cb[f]: the 48 de-interleaved hard
+// decisions of frame f (bit j = coded bit j; 0 for a row without a frame).  sig[f] = its 24 decoded bits (bit t = decoded
+// bit t), wave-uniform.  The path metrics of the four frames share one register per lane, a byte each: a metric is at most
+// 48, and the "unreachable" start value only has to exceed that (64; the oracle's 2^28 orders every comparison the same
+// way: each path has one origin) -- so no byte ever reaches 128 and the byte-wise compare is one subtraction with a guard
+// bit: byte f of (m0 + 0x7f7f7f7f) - m1 has its top bit set iff m1 < m0.  Survivor words go through `scr` (4 x 24 x 8 B of
+// wave-private LDS); the trace-back runs in lanes 0..3, one frame each.
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+__device__ __forceinline__ void viterbi_signal4(const uint64_t (&cb)[4], int lane, uint64_t* scr, uint32_t (&sig)[4])
 {
     const int s = lane, u = s & 1, p0 = s >> 1, p1 = (s >> 1) | 32;
     const int f0 = (p0 << 1) | u, f1 = (p1 << 1) | u;
-    const int a0 = __builtin_popcount(f0 & 0155) & 1, b0 = __builtin_popcount(f0 & 0117) & 1;
-    const int a1 = __builtin_popcount(f1 & 0155) & 1, b1 = __builtin_popcount(f1 & 0117) & 1;
-    int pm = (s == 0) ? 0 : (1 << 24);
+    const uint32_t A0 = (__builtin_popcount(f0 & 0155) & 1) * 0x01010101u, B0 = (__builtin_popcount(f0 & 0117) & 1) * 0x01010101u;
+    const uint32_t A1 = (__builtin_popcount(f1 & 0155) & 1) * 0x01010101u, B1 = (__builtin_popcount(f1 & 0117) & 1) * 0x01010101u;
+    uint32_t pm = (s == 0) ? 0u : 0x40404040u;
 #pragma unroll 1
     for (int t = 0; t < 24; t++) {
-        int ra = (int)((cbits >> (2 * t)) & 1), rb = (int)((cbits >> (2 * t + 1)) & 1);
-        int m0 = __shfl(pm, p0, 64) + (ra != a0) + (rb != b0);
-        int m1 = __shfl(pm, p1, 64) + (ra != a1) + (rb != b1);
-        bool sel = m1 < m0;
-        pm = sel ? m1 : m0;
-        uint64_t d = __ballot(sel);
-        if (lane == 0) scr[t] = d;
+        // received bits of step t, frame f in byte f (scalar unit)
+        uint32_t ra = 0, rb = 0;
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const uint32_t two = (uint32_t)(cb[f] >> (2 * t)) & 3u;
+            ra |= (two & 1u) << (8 * f);
+            rb |= (two >> 1) << (8 * f);
+        }
+        const uint32_t m0 = (uint32_t)__shfl((int)pm, p0, 64) + ((ra ^ A0) + (rb ^ B0));
+        const uint32_t m1 = (uint32_t)__shfl((int)pm, p1, 64) + ((ra ^ A1) + (rb ^ B1));
+        const uint32_t top = ((m0 + 0x7f7f7f7fu) - m1) & 0x80808080u;     // byte f: 0x80 iff m1 < m0
+        const uint32_t mask = (top - (top >> 7)) | top;                   // ... 0xff
+        pm = (m1 & mask) | (m0 & ~mask);
+        const uint64_t d0 = __ballot((top & 0x00000080u) != 0), d1 = __ballot((top & 0x00008000u) != 0);
+        const uint64_t d2 = __ballot((top & 0x00800000u) != 0), d3 = __ballot((top & 0x80000000u) != 0);
+        if (lane == 0) { scr[t] = d0; scr[24 + t] = d1; scr[48 + t] = d2; scr[72 + t] = d3; }
     }
-    int key = (pm << 6) | s;      // best final state: smallest metric, lowest index on ties
+    // best final state per frame: smallest metric, lowest index on ties -- keys (metric << 6 | state) of two frames per register
+    uint32_t k01 = ((((pm & 0xffu) << 6) | (uint32_t)s)) | (((((pm >> 8) & 0xffu) << 6) | (uint32_t)s) << 16);
+    uint32_t k23 = (((((pm >> 16) & 0xffu) << 6) | (uint32_t)s)) | ((((pm >> 24) << 6) | (uint32_t)s) << 16);
 #pragma unroll
     for (int k = 1; k < 64; k <<= 1) {
-        int o = __shfl_xor(key, k, 64);
-        key = o < key ? o : key;
+        k01 = pk_min_u16(k01, (uint32_t)__shfl_xor((int)k01, k, 64));
+        k23 = pk_min_u16(k23, (uint32_t)__shfl_xor((int)k23, k, 64));
     }
-    int st = key & 63;
     __builtin_amdgcn_wave_barrier();
-    uint64_t mine = (lane < 24) ? scr[lane] : 0;      // lane t holds survivor word t
-    uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+    // trace-back: lane f = frame f (the other lanes repeat frames 0..3 and are not read)
+    const int fr = lane & 3;
+    const uint32_t kk = (fr & 2) ? k23 : k01;
+    int st = (int)(((fr & 1) ? (kk >> 16) : kk) & 63u);
+    const uint64_t* row = scr + 24 * fr;
     uint32_t bits = 0;
-#pragma unroll 1
+#pragma unroll 6
     for (int t = 23; t >= 0; t--) {
         bits |= (uint32_t)(st & 1) << t;
-        uint32_t dlo = (uint32_t)__builtin_amdgcn_readlane((int)lo, t);
-        uint32_t dhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, t);
-        uint32_t h = (st < 32 ? (dlo >> st) : (dhi >> (st - 32))) & 1u;
+        const uint32_t h = (uint32_t)(row[t] >> st) & 1u;
         st = (st >> 1) | (int)(h << 5);
     }
     __builtin_amdgcn_wave_barrier();
-    return bits;
+#pragma unroll
+    for (int f = 0; f < 4; f++) sig[f] = (uint32_t)__builtin_amdgcn_readlane((int)bits, f);
 }
 
 __device__ __forceinline__ bool parse_signal(uint32_t bits, int& enc, int& len)
@@ -1105,19 +1122,25 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #pragma unroll
                 for (int j = 0; j < 4; j++) bal[j] = __ballot(carrier[j] >= 0 && Y[j].re > 0.0f);
                 const uint64_t actmask = __ballot(act);
-#pragma unroll 1
+                // lane jj < 48 picks de-interleaved bit jj = carrier bit 3 (jj mod 16) + jj / 16 of every frame
+                const int dsrc = lane < 48 ? 3 * (lane & 15) + (lane >> 4) : 63;      // bit 63 of cm is 0
+                uint64_t de[4];
+#pragma unroll
                 for (int f = 0; f < 4; f++) {
-                    if (!((actmask >> (16 * f)) & 1)) continue;
                     uint64_t b = 0;
 #pragma unroll
                     for (int j = 0; j < 4; j++) b |= ((bal[j] >> (16 * f)) & 0xffffull) << (16 * j);
-                    uint64_t cm = ((b >> 6) & 0x1full) | (((b >> 12) & 0x1fffull) << 5) |
-                                  (((b >> 26) & 0x3full) << 18) | (((b >> 33) & 0x3full) << 24) |
-                                  (((b >> 40) & 0x1fffull) << 30) | (((b >> 54) & 0x1full) << 43);
-                    uint64_t de = 0;
-#pragma unroll 1
-                    for (int jj = 0; jj < 48; jj++) de |= ((cm >> (3 * (jj % 16) + jj / 16)) & 1ull) << jj;
-                    uint32_t sig = viterbi_signal(de, lane, reinterpret_cast<uint64_t*>(qlds));
+                    const uint64_t cm = ((b >> 6) & 0x1full) | (((b >> 12) & 0x1fffull) << 5) |
+                                        (((b >> 26) & 0x3full) << 18) | (((b >> 33) & 0x3full) << 24) |
+                                        (((b >> 40) & 0x1fffull) << 30) | (((b >> 54) & 0x1full) << 43);
+                    de[f] = __ballot(((cm >> dsrc) & 1ull) != 0);
+                }
+                uint32_t sig4[4];
+                viterbi_signal4(de, lane, reinterpret_cast<uint64_t*>(qlds), sig4);
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    if (!((actmask >> (16 * f)) & 1)) continue;
+                    const uint32_t sig = sig4[f];
                     int e = 0, len = 0;
                     bool ok = parse_signal(sig, e, len);
                     if (row == f) {
