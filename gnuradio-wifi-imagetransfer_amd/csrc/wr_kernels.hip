@@ -182,13 +182,25 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
             pf[f] = { iq + off, has ? len : 0l, -1, 0, 0.0f, false, has ? (long)slot : -1l };
             detect_load(pf[f].x, pf[f].n_samp, lane, da[f]);
         }
+        c32 A4[4];
 #pragma unroll
         for (int f = 0; f < 4; f++) {
-            c32 A_t = { 0, 0 };
-            const int t = detect_first(pf[f].x, pf[f].n_samp, prm.threshold, prm.min_plateau, lane, da[f], A_t);
-            pf[f].t = t;
+            A4[f] = { 0, 0 };
+            pf[f].t = detect_first(pf[f].x, pf[f].n_samp, prm.threshold, prm.min_plateau, lane, da[f], A4[f]);
+        }
+        // coarse CFO of the four slots in ONE pass of the arctangent: row f of the wave works on slot f
+        float cfo4;
+        {
+            const int row = lane >> 4;
+            const float y = row == 0 ? A4[0].im : row == 1 ? A4[1].im : row == 2 ? A4[2].im : A4[3].im;
+            const float x = row == 0 ? A4[0].re : row == 1 ? A4[1].re : row == 2 ? A4[2].re : A4[3].re;
+            cfo4 = sp_atan2(y, x) / 16.0f;
+        }
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            const int t = (int)pf[f].t;
             if (t >= 0) {
-                pf[f].cfo_c = sp_atan2(A_t.im, A_t.re) / 16.0f;
+                pf[f].cfo_c = bcast(cfo4, 16 * f);
                 long L = pf[f].n_samp - (t - 16);
                 if (L > WIFIRX_MAX_SAMPLES) L = WIFIRX_MAX_SAMPLES;
                 pf[f].L = L;

@@ -449,32 +449,31 @@ __device__ __forceinline__ void lts_top4_pair(float ex, int lag, int lane, const
     }
 }
 
-// sync_long's pair search over the (up to) four largest peaks of a frame: frame start and fine CFO.  Returns false when no
-// LTS pair was found.
-__device__ __forceinline__ bool lts_pair_search(const int (&top_off)[4], const c32 (&top_val)[4], int& fs, float& cfo_f)
+// sync_long's pair search over the (up to) four largest peaks of a frame: the frame start and the two peaks whose phase
+// difference is the fine CFO (cfo_f = arg(conj(first) second) / diff, formed by the caller for both frames of a pair in one
+// pass).  Returns the distance of the chosen pair (64, or the last 63 / 65 seen), 0 when no LTS pair was found.
+__device__ __forceinline__ int lts_pair_search(const int (&top_off)[4], const c32 (&top_val)[4], int& fs, c32& first, c32& second)
 {
     int found = 0;
     fs = WIFIRX_SYNC_LENGTH;
-    cfo_f = 0.0f;
+    first = { 0.0f, 0.0f };
+    second = { 0.0f, 0.0f };
 #pragma unroll
     for (int i = 0; i < 3; i++) {
 #pragma unroll
         for (int k = i + 1; k < 4; k++) {
             if (found == 64) continue;
-            int oi = top_off[i], ok = top_off[k];
-            c32 first = oi > ok ? top_val[k] : top_val[i];
-            c32 second = oi > ok ? top_val[i] : top_val[k];
-            int diff = oi > ok ? oi - ok : ok - oi;
+            const int oi = top_off[i], ok = top_off[k];
+            const int diff = oi > ok ? oi - ok : ok - oi;
             if ((diff == 64 || diff == 63 || diff == 65) && oi >= 0 && ok >= 0) {      // -1: fewer than four valid lags
-                float pr = fma_(first.im, second.im, first.re * second.re);
-                float pi = fma_(first.im, second.re, -(first.re * second.im));
+                first = oi > ok ? top_val[k] : top_val[i];
+                second = oi > ok ? top_val[i] : top_val[k];
                 fs = oi < ok ? oi : ok;
-                cfo_f = sp_atan2(pi, pr) / (float)diff;
                 found = diff;
             }
         }
     }
-    return found != 0;
+    return found;
 }
 
 // What the preamble phase hands to the symbol phase.  One copy per lane, uniform inside a row: row f
@@ -531,6 +530,21 @@ __device__ __forceinline__ void preamble_pair_finish(const PreFrame& f0, const P
         ex = lts_exact_pair(lds, lane, cand[0], cand[1], lag);
         lts_top4_pair(ex, lag, lane, n_cand, top_off, top_val);
     }
+    // the pair search of both frames, then ONE pass of the arctangent for the two fine CFOs (even lanes: frame 0, odd: 1)
+    int fs2[2] = { 0, 0 }, found2[2] = { 0, 0 };
+    c32 fi[2] = { { 0.0f, 0.0f }, { 0.0f, 0.0f } }, se[2] = { { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+        if (pf[e].out >= 0 && pf[e].t >= 0 && pf[e].search) found2[e] = lts_pair_search(top_off[e], top_val[e], fs2[e], fi[e], se[e]);
+    float cfo2;
+    {
+        const bool odd = lane & 1;
+        const c32 a = odd ? fi[1] : fi[0], b = odd ? se[1] : se[0];
+        const int dv = odd ? found2[1] : found2[0];
+        const float pr = fma_(a.im, b.im, a.re * b.re);
+        const float pi = fma_(a.im, b.re, -(a.re * b.im));
+        cfo2 = sp_atan2(pi, pr) / (float)(dv ? dv : 64);
+    }
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         if (pf[e].out < 0) continue;
@@ -540,9 +554,9 @@ __device__ __forceinline__ void preamble_pair_finish(const PreFrame& f0, const P
         if (pf[e].t >= 0) {
             flags = WIFIRX_F_DETECTED | WIFIRX_F_TRUNCATED;
             if (pf[e].search) {
-                const bool ok = lts_pair_search(top_off[e], top_val[e], fs, cfo_f);
+                const bool ok = found2[e] != 0;
                 flags = ok ? (WIFIRX_F_DETECTED | WIFIRX_F_SYNC) : WIFIRX_F_DETECTED;
-                if (!ok) { fs = 0; cfo_f = 0.0f; }
+                if (ok) { fs = fs2[e]; cfo_f = bcast(cfo2, e); }
             }
         }
         if ((lane >> 4) == 2 * p + e) {
