@@ -296,45 +296,63 @@ __device__ __forceinline__ void lts_corr_pair_q8(const float* ylds, int lane, wr
 // exact and |corr_q|^2 = fma(im, im, re re) is the same number on the CPU; it is >= +0 and no NaN, so its bit pattern
 // orders like a signed integer; already-taken entries and the lanes that hold imaginary parts are -1.  Per round: one
 // integer max over the wave, then the lowest lag that holds it (per register the first lane of a ballot; lag = base +
-// lane).  The two largest; when they are not exactly 64 lags apart, the eight largest.  Returns their number.
-__device__ __forceinline__ int lts_candidates(const int (&cq)[10], int lane, int (&cand)[8])
+// lane).  The two largest; when they are not exactly 64 lags apart, the eight largest; n_cand = their number.
+__device__ __forceinline__ void lts_candidates2(const int (&cq0)[10], const int (&cq1)[10], const bool (&run)[2], int lane,
+                                                int (&cand)[2][8], int (&n_cand)[2])
 {
-    int km[10];
+    // both frames of the pair round by round: their reductions are independent chains the scheduler interleaves
+    int km[2][10];
     const bool holds_re = (lane & 8) == 0;
 #pragma unroll
-    for (int n = 0; n < 10; n++) {
-        const int ci = __builtin_bit_cast(int, dpp_zero<0x108>(__builtin_bit_cast(float, cq[n])));      // row_shl:8: the imaginary part from lane + 8
-        const float fr = (float)cq[n], fi = (float)ci;
-        const float mag = fma_(fi, fi, fr * fr);
-        km[n] = holds_re ? (int)__float_as_uint(mag) : -1;
-    }
-    int n_cand = 0;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        cand[r] = 0;
-        if (r >= 2) {
-            const int d01 = cand[0] > cand[1] ? cand[0] - cand[1] : cand[1] - cand[0];
-            if (d01 == 64) continue;                            // wave-uniform: the usual case, the two LTS peaks
-        }
-        int m = km[0];
-#pragma unroll
-        for (int n = 1; n < 10; n++) m = km[n] > m ? km[n] : m;
-        const int best = wave_max_int(m);
-        int w = 0x7fffffff;
+    for (int e = 0; e < 2; e++) {
 #pragma unroll
         for (int n = 0; n < 10; n++) {
-            const uint64_t hit = __ballot(km[n] == best);
-            const int lag = 64 * (n >> 1) + 8 * (n & 1) + (int)__builtin_ctzll(hit | (1ull << 63));
-            if (hit) w = lag < w ? lag : w;
+            const int c = e ? cq1[n] : cq0[n];
+            const int ci = __builtin_bit_cast(int, dpp_zero<0x108>(__builtin_bit_cast(float, c)));      // row_shl:8: the imaginary part from lane + 8
+            const float fr = (float)c, fi = (float)ci;
+            const float mag = fma_(fi, fi, fr * fr);
+            km[e][n] = holds_re ? (int)__float_as_uint(mag) : -1;
         }
-        const int wn = ((w >> 6) << 1) | ((w >> 3) & 1), wl = w & 0x37;
-#pragma unroll
-        for (int n = 0; n < 10; n++)
-            if (n == wn && lane == wl) km[n] = -1;
-        cand[r] = w;
-        n_cand = r + 1;
     }
-    return n_cand;
+    n_cand[0] = n_cand[1] = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        bool need[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            cand[e][r] = 0;
+            need[e] = run[e];
+            if (r >= 2) {
+                const int d01 = cand[e][0] > cand[e][1] ? cand[e][0] - cand[e][1] : cand[e][1] - cand[e][0];
+                if (d01 == 64) need[e] = false;                 // wave-uniform: the usual case, the two LTS peaks
+            }
+        }
+        if (!(need[0] || need[1])) continue;
+        int w[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {                           // no branch in here: a frame that needs no further round just idles along
+            int m = km[e][0];
+#pragma unroll
+            for (int n = 1; n < 10; n++) m = km[e][n] > m ? km[e][n] : m;
+            const int best = wave_max_int(m);
+            int wl = 0x7fffffff;
+#pragma unroll
+            for (int n = 0; n < 10; n++) {
+                const uint64_t hit = __ballot(km[e][n] == best);
+                const int lag = 64 * (n >> 1) + 8 * (n & 1) + (int)__builtin_ctzll(hit | (1ull << 63));
+                const int cl = hit ? lag : 0x7fffffff;
+                wl = cl < wl ? cl : wl;
+            }
+            w[e] = wl;
+            const int wn = ((wl >> 6) << 1) | ((wl >> 3) & 1), wlane = wl & 0x37;
+#pragma unroll
+            for (int n = 0; n < 10; n++)
+                if (n == wn && lane == wlane) km[e][n] = -1;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+            if (need[e]) { cand[e][r] = w[e]; n_cand[e] = r + 1; }
+    }
 }
 
 // Stage 2 for the pair: the float32 correlation values of the candidates, on ONE tile of v_mfma_f32_16x16x4_f32: row
@@ -509,23 +527,14 @@ __device__ __forceinline__ void preamble_pair_finish(const PreFrame& f0, const P
     if (run[0] || run[1]) {
         wr_i4 acc[5];
         lts_corr_pair_q8(lds, lane, acc);
+        int cq0[10], cq1[10];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
+        for (int n = 0; n < 8; n++) cq0[n] = acc[n >> 2][n & 3];
+        cq0[8] = acc[2][0]; cq0[9] = acc[2][1];
+        cq1[0] = acc[2][2]; cq1[1] = acc[2][3];
 #pragma unroll
-            for (int c = 0; c < 8; c++) cand[e][c] = 0;
-            if (!run[e]) continue;
-            int cq[10];
-            if (e == 0) {
-#pragma unroll
-                for (int n = 0; n < 8; n++) cq[n] = acc[n >> 2][n & 3];
-                cq[8] = acc[2][0]; cq[9] = acc[2][1];
-            } else {
-                cq[0] = acc[2][2]; cq[1] = acc[2][3];
-#pragma unroll
-                for (int n = 2; n < 10; n++) cq[n] = acc[3 + ((n - 2) >> 2)][(n - 2) & 3];
-            }
-            n_cand[e] = lts_candidates(cq, lane, cand[e]);
-        }
+        for (int n = 2; n < 10; n++) cq1[n] = acc[3 + ((n - 2) >> 2)][(n - 2) & 3];
+        lts_candidates2(cq0, cq1, run, lane, cand, n_cand);
         int lag;
         ex = lts_exact_pair(lds, lane, cand[0], cand[1], lag);
         lts_top4_pair(ex, lag, lane, n_cand, top_off, top_val);
