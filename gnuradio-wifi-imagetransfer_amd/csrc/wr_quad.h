@@ -442,8 +442,14 @@ __device__ __forceinline__ void lts_top4_pair(float ex, int lag, int lane, const
     const float mag = fma_(im, im, ex * ex);
     const int nc = e ? n_cand[1] : n_cand[0];
     int key = (lane < 32 && part == 0 && c < nc && mag >= 0.0f) ? (int)__float_as_uint(mag) : -1;
+    const int n_rounds = n_cand[0] > n_cand[1] ? n_cand[0] : n_cand[1];      // wave-uniform; usually 2
 #pragma unroll
     for (int r = 0; r < 4; r++) {
+        if (r >= n_rounds) {                                    // no candidate left in either frame: what the round would find
+#pragma unroll
+            for (int f = 0; f < 2; f++) { top_off[f][r] = -1; top_val[f][r] = { 0.0f, 0.0f }; }
+            continue;
+        }
         const int m = row_max16(key);
         const int b0 = __builtin_amdgcn_readlane(m, 15), b1 = __builtin_amdgcn_readlane(m, 31);
         const int best = e ? b1 : b0;
