@@ -214,38 +214,49 @@ __device__ __forceinline__ int quant8(float x, float scale)
 __device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const PreFrame& f1, const PreSamples& s0,
                                                        const PreSamples& s1, float* ylds, int lane)
 {
+    if (!(f0.search || f1.search)) return;                  // wave-uniform
+    // Both frames in one piece of straight-line code: their chains (two sincos, the carried phasor, the maximum over the
+    // wave) are independent and interleave.  A frame without a search runs along on zeros; nothing reads its area.
+    c32 yv[2][6];
+    uint32_t mx[2] = { 0u, 0u };
+    // spec rule 5a: the phasor of sample m = 64 p + l is that of sample l (exact: sp_sincos of the float angle) carried
+    // p times by exp(-j float(cfo_c 64)) -- two sincos per lane and frame instead of six
+    c32 wl[2], w64[2];
 #pragma unroll
     for (int e = 0; e < 2; e++) {
-        const PreFrame& f = e ? f1 : f0;
-        const PreSamples& ps = e ? s1 : s0;
-        if (!f.search) continue;                            // wave-uniform
-        c32 yv[6];
-        uint32_t mx = 0;
-        // spec rule 5a: the phasor of sample m = 64 p + l is that of sample l (exact: sp_sincos of the float angle) carried
-        // p times by exp(-j float(cfo_c 64)) -- two sincos per lane and frame instead of six
-        c32 wl, w64;
-        sp_sincos(-f.cfo_c * (float)lane, wl.im, wl.re);
-        sp_sincos(-f.cfo_c * 64.0f, w64.im, w64.re);
+        const float cfo = e ? f1.cfo_c : f0.cfo_c;
+        sp_sincos(-cfo * (float)lane, wl[e].im, wl[e].re);
+        sp_sincos(-cfo * 64.0f, w64[e].im, w64[e].re);
+    }
 #pragma unroll
-        for (int pass = 0; pass < 6; pass++) {
-            const int m = pass * 64 + lane;
-            if (pass) wl = sp_cmul(wl, w64);
-            const c32 y = sp_cmul(ps.xs[pass], wl);
+    for (int pass = 0; pass < 6; pass++) {
+        const int m = pass * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            if (pass) wl[e] = sp_cmul(wl[e], w64[e]);
+            const c32 y = sp_cmul(e ? s1.xs[pass] : s0.xs[pass], wl[e]);
             *reinterpret_cast<float2*>(ylds + WR_PRE_FRAME_FLOATS * e + 2 * m) = make_float2(y.re, y.im);
-            yv[pass] = y;
+            yv[e][pass] = y;
             const uint32_t br = __float_as_uint(y.re) & 0x7fffffffu, bi = __float_as_uint(y.im) & 0x7fffffffu;
-            mx = br > mx ? br : mx;
-            mx = bi > mx ? bi : mx;
+            mx[e] = br > mx[e] ? br : mx[e];
+            mx[e] = bi > mx[e] ? bi : mx[e];
         }
-        // the 8-bit image: a power of two puts the largest component of the frame into [64, 128)
-        const int E = wave_max_int((int)mx) >> 23;           // largest biased exponent (255: an Inf or NaN among the samples)
+    }
+    // the 8-bit image: a power of two puts the largest component of the frame into [64, 128)
+    float scale[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int E = wave_max_int((int)mx[e]) >> 23;        // largest biased exponent (255: an Inf or NaN among the samples)
         const int sfield = 260 - E > 254 ? 254 : 260 - E;
-        const float scale = __uint_as_float((uint32_t)sfield << 23);
+        scale[e] = __uint_as_float((uint32_t)sfield << 23);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
         uint8_t* q8 = reinterpret_cast<uint8_t*>(ylds + WR_PRE_Q8) + WR_PRE_Q8_FRAME * e;
 #pragma unroll
         for (int pass = 0; pass < 6; pass++) {
             const int m = pass * 64 + lane;
-            const int qr = quant8(yv[pass].re, scale), qi = quant8(yv[pass].im, scale);
+            const int qr = quant8(yv[e][pass].re, scale[e]), qi = quant8(yv[e][pass].im, scale[e]);
             *reinterpret_cast<uint16_t*>(q8 + 2 * m) = (uint16_t)((qr & 0xff) | ((qi & 0xff) << 8));
         }
         if (lane < 16) *reinterpret_cast<uint32_t*>(q8 + 768 + 4 * lane) = 0u;
