@@ -85,16 +85,17 @@ __device__ __forceinline__ void viterbi_signal4(const uint64_t (&cb)[4], int lan
     const uint32_t A0 = (__builtin_popcount(f0 & 0155) & 1) * 0x01010101u, B0 = (__builtin_popcount(f0 & 0117) & 1) * 0x01010101u;
     const uint32_t A1 = (__builtin_popcount(f1 & 0155) & 1) * 0x01010101u, B1 = (__builtin_popcount(f1 & 0117) & 1) * 0x01010101u;
     uint32_t pm = (s == 0) ? 0u : 0x40404040u;
+    // received bits, frame f in byte f: lane t forms those of step t once, the loop fetches them with two lane reads
+    uint32_t ra_l = 0, rb_l = 0;
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const uint32_t two = (uint32_t)(cb[f] >> (2 * (lane & 31))) & 3u;
+        ra_l |= (two & 1u) << (8 * f);
+        rb_l |= (two >> 1) << (8 * f);
+    }
 #pragma unroll 1
     for (int t = 0; t < 24; t++) {
-        // received bits of step t, frame f in byte f (scalar unit)
-        uint32_t ra = 0, rb = 0;
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-            const uint32_t two = (uint32_t)(cb[f] >> (2 * t)) & 3u;
-            ra |= (two & 1u) << (8 * f);
-            rb |= (two >> 1) << (8 * f);
-        }
+        const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane((int)ra_l, t), rb = (uint32_t)__builtin_amdgcn_readlane((int)rb_l, t);
         const uint32_t m0 = (uint32_t)__shfl((int)pm, p0, 64) + ((ra ^ A0) + (rb ^ B0));
         const uint32_t m1 = (uint32_t)__shfl((int)pm, p1, 64) + ((ra ^ A1) + (rb ^ B1));
         const uint32_t top = ((m0 + 0x7f7f7f7fu) - m1) & 0x80808080u;     // byte f: 0x80 iff m1 < m0
