@@ -308,7 +308,9 @@ __device__ __forceinline__ void lts_corr_pair_q8(const float* ylds, int lane, wr
 // exact and |corr_q|^2 = fma(im, im, re re) is the same number on the CPU; it is >= +0 and no NaN, so its bit pattern
 // orders like a signed integer; already-taken entries and the lanes that hold imaginary parts are -1.  Per round: one
 // integer max over the wave, then the lowest lag that holds it (per register the first lane of a ballot; lag = base +
-// lane).  The two largest; when they are not exactly 64 lags apart, the eight largest; n_cand = their number.
+// lane).  The two largest when they are exactly 64 lags apart and the third largest value is below 7/8 of the second
+// (spec rule 6: no rounding of the integer stage can then have changed the leaders); otherwise the eight largest; n_cand =
+// their number.
 __device__ __forceinline__ void lts_candidates2(const int (&cq0)[10], const int (&cq1)[10], const bool (&run)[2], int lane,
                                                 int (&cand)[2][8], int (&n_cand)[2])
 {
@@ -327,30 +329,39 @@ __device__ __forceinline__ void lts_candidates2(const int (&cq0)[10], const int 
         }
     }
     n_cand[0] = n_cand[1] = 0;
+    bool need[2] = { run[0], run[1] };
+    int second[2] = { 0, 0 };                                   // the second largest |corr_q|^2 (bit pattern)
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        bool need[2];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            cand[e][r] = 0;
-            need[e] = run[e];
-            if (r >= 2) {
-                const int d01 = cand[e][0] > cand[e][1] ? cand[e][0] - cand[e][1] : cand[e][1] - cand[e][0];
-                if (d01 == 64) need[e] = false;                 // wave-uniform: the usual case, the two LTS peaks
-            }
-        }
+        for (int e = 0; e < 2; e++) cand[e][r] = 0;
         if (!(need[0] || need[1])) continue;
-        int w[2];
+        int best[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {                           // no branch in here: a frame that needs no further round just idles along
             int m = km[e][0];
 #pragma unroll
             for (int n = 1; n < 10; n++) m = km[e][n] > m ? km[e][n] : m;
-            const int best = wave_max_int(m);
+            best[e] = wave_max_int(m);
+            if (r == 1) second[e] = best[e];
+        }
+        if (r == 2) {
+            // the two leaders stand when they are 64 lags apart and the third largest value is below 7/8 of the second
+            // (wave-uniform: the usual case); otherwise the eight largest are the candidates
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int d01 = cand[e][0] > cand[e][1] ? cand[e][0] - cand[e][1] : cand[e][1] - cand[e][0];
+                if (d01 == 64 && __int_as_float(best[e]) < 0.875f * __int_as_float(second[e])) need[e] = false;
+            }
+            if (!(need[0] || need[1])) continue;
+        }
+        int w[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
             int wl = 0x7fffffff;
 #pragma unroll
             for (int n = 0; n < 10; n++) {
-                const uint64_t hit = __ballot(km[e][n] == best);
+                const uint64_t hit = __ballot(km[e][n] == best[e]);
                 const int lag = 64 * (n >> 1) + 8 * (n & 1) + (int)__builtin_ctzll(hit | (1ull << 63));
                 const int cl = hit ? lag : 0x7fffffff;
                 wl = cl < wl ? cl : wl;

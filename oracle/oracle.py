@@ -30,7 +30,8 @@ F_DETECTED, F_SYNC, F_SIGNAL, F_COMPLETE, F_LLR, F_DECODED, F_CRC_OK = 1, 2, 4, 
 class Params(C.Structure):
     _fields_ = [("bandwidth", C.c_double), ("frequency", C.c_double), ("threshold", C.c_float),
                 ("min_plateau", C.c_int32), ("math_mode", C.c_int32), ("max_sym", C.c_int32),
-                ("llr_bits", C.c_int32), ("chan_est", C.c_int32), ("llr_csi", C.c_int32)]
+                ("llr_bits", C.c_int32), ("chan_est", C.c_int32), ("llr_csi", C.c_int32),
+                ("lts_search", C.c_int32), ("pad_", C.c_int32), ("dbg_top4", C.c_void_p), ("dbg_mag4", C.c_void_p)]
 
 
 def build(force: bool = False) -> str:
@@ -88,8 +89,10 @@ def _p(a):
 
 
 def make_params(bandwidth=20e6, frequency=5.89e9, threshold=0.56, min_plateau=2,
-                math_mode=MATH_SPEC, max_sym=64, llr_bits=0, chan_est=0, llr_csi=0) -> Params:
-    return Params(bandwidth, frequency, threshold, min_plateau, math_mode, max_sym, llr_bits, chan_est, llr_csi)
+                math_mode=MATH_SPEC, max_sym=64, llr_bits=0, chan_est=0, llr_csi=0, lts_search=0) -> Params:
+    """lts_search (SPEC mode): 0 = rule 6 as the kernels run it, 1 = the exhaustive float32 search over all 320 lags."""
+    return Params(bandwidth, frequency, threshold, min_plateau, math_mode, max_sym, llr_bits, chan_est, llr_csi,
+                  lts_search, 0, None, None)
 
 
 def demod_batch(iq: np.ndarray, slot_len: int, prm: Params, want_eq=False, n_threads=1, want_csi=False):

@@ -53,6 +53,12 @@ typedef struct orc_params {
     int32_t llr_bits;     /* 0: no llr */
     int32_t chan_est;     /* WIFIRX_EQ_LS / LMS / COMB / STA */
     int32_t llr_csi;      /* 1: every LLR is multiplied by |H|^2 of its sub-carrier (LS estimate of the preamble) */
+    int32_t lts_search;   /* SPEC mode only.  0: rule 6 as the kernels run it (candidates from the 8-bit search);
+                           * 1: the float32 values of ALL 320 lags, the four largest of those -- sync_long's exhaustive
+                           *    search in the spec's arithmetic.  The tests compare the two (tests/test_lts_rule6.py). */
+    int32_t pad_;
+    int32_t* dbg_top4;    /* test hook of orc_frame (single-threaded callers only): the four lags handed to the pair search */
+    float*   dbg_mag4;    /* ... and their magnitudes (|corr|^2 in SPEC mode, |corr| in LIBM mode); NULL: off */
 } orc_params;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -654,8 +660,12 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
          * Stage 1.  The 384 copied samples are scaled by a power of two that puts the largest component into [64, 128)
          * and rounded to integers in [-127, 127] (NaN -> 0); the taps are rint(64 l) (WR_LTS_Q8).  For every lag the
          * integer correlation conj(lq) yq, its squared magnitude in float32 (the integers are below 2^24: exact
-         * conversions).  The two largest (lowest lag first among equals) are the candidates; when they are not exactly 64
-         * lags apart, the eight largest are. */
+         * conversions).  The two largest (lowest lag first among equals) are the candidates when they are exactly 64 lags
+         * apart AND the third largest squared magnitude is below 7/8 of the second (float32 product) -- then no rounding
+         * of the integer stage can have changed which two lags lead, and sync_long's pair search ends at that pair
+         * whatever ranks 3 and 4 are; otherwise the eight largest are the candidates.  (Round 2 took the top two whenever
+         * they were 64 apart: tests/campaigns/lts_rule6.py found 4 frames in 154 000 at 0..8 dB, two equally strong paths,
+         * where a third lag within 0.3 % led the float32 ranking and the exhaustive search chose another pair.) */
         int E = 0;                                               /* largest biased exponent among the 768 components */
         for (int m = 0; m < WIFIRX_SYNC_LENGTH + 64; m++) {
             uint32_t br, bi;
@@ -687,7 +697,10 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             const float fr_ = (float)cr, fi_ = (float)ci;
             mag1[i] = fmaf(fi_, fi_, fr_ * fr_);
         }
-        int cand[8], n_cand = 0;
+        int cand[WIFIRX_SYNC_LENGTH], n_cand = 0;
+        if (prm->lts_search == 1) {                              /* every lag is a candidate: the exhaustive float32 search */
+            for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) cand[n_cand++] = i;
+        } else
         for (int r = 0; r < 8; r++) {
             int best = -1;
             for (int i = 0; i < WIFIRX_SYNC_LENGTH; i++) {
@@ -696,8 +709,9 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 if (used) continue;
                 if (best < 0 || mag1[i] > mag1[best]) best = i;
             }
+            if (r == 2 && abs(cand[0] - cand[1]) == 64 && mag1[best] < 0.875f * mag1[cand[1]])
+                break;                                          /* the usual case: the two LTS peaks, clear of every other lag */
             cand[n_cand++] = best;
-            if (r == 1 && abs(cand[0] - cand[1]) == 64) break;   /* the usual case: the two LTS peaks */
         }
         /* Stage 2.  The candidates' correlation values in float32: lag i = 8a + b reads the 144 floats (72 samples, re/im
          * interleaved) from sample 8a on; float phi = 2m + part meets tap k = m - b (coefficient 0 outside 0..63).  Both
@@ -759,6 +773,12 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 if (best < 0 || mag[i] > mag[best]) best = i;
             }
             top[r] = best;
+        }
+    }
+    if (prm->dbg_top4) {                                /* test hook: the four peaks the pair search sees, and their magnitudes */
+        for (int r = 0; r < 4; r++) {
+            prm->dbg_top4[r] = top[r];
+            if (prm->dbg_mag4) prm->dbg_mag4[r] = top[r] >= 0 ? mag[top[r]] : 0.0f;
         }
     }
     int   fs = WIFIRX_SYNC_LENGTH, found = 0;

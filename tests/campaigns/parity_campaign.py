@@ -21,7 +21,10 @@ sys.path.insert(0, ROOT)
 from wifirx import capi, txgen  # noqa: E402
 
 
-def make_batch(n, slot_len, seed, max_len=1200):
+SNRS = (6.0, 12.0, 20.0, 28.0, 35.0)
+
+
+def make_batch(n, slot_len, seed, max_len=1200, snrs=SNRS):
     rng = np.random.default_rng(seed)
     taps_set = np.load(os.path.join(ROOT, "tests", "golden", "sv_taps.npy"))
     iq = np.zeros((n, slot_len), np.complex64)
@@ -36,7 +39,7 @@ def make_batch(n, slot_len, seed, max_len=1200):
         psdu = txgen.make_psdus(g, plen, seed=seed * 100003 + k)
         tx = txgen.encode_psdus(psdu, enc, seeds=[int(s) for s in rng.integers(1, 128, g)])
         for r in range(g):
-            snr = float(rng.choice([6.0, 12.0, 20.0, 28.0, 35.0]))
+            snr = float(rng.choice(list(snrs)))
             taps = taps_set[int(rng.integers(0, taps_set.shape[0]))][None, :] if rng.random() < 0.4 else None
             iq[k + r] = txgen.impair(tx.samples[r:r + 1], snr, cfo=float(rng.uniform(-0.04, 0.04)),
                                      lead=int(rng.integers(0, 250)), total=slot_len, seed=int(rng.integers(1 << 30)),
@@ -45,50 +48,65 @@ def make_batch(n, slot_len, seed, max_len=1200):
     return iq.reshape(-1)
 
 
+def run(n=20000, seed=1, long_frames=False, snrs=SNRS, equalisers=(0, 1, 2, 3), decode_small_max=None):
+    """One campaign; returns the result dictionary (`all_bit_exact` is the verdict).  decode_small_max: forces decode_mac's
+    kernel choice (0: the throughput decoder with 128 frames per wave for every batch; None: the library's default)."""
+    slot_len, max_sym, llr_bits = (45056, 511, 1) if long_frames else (8192, 96, 6)
+    from oracle import oracle as orc
+    t0 = time.perf_counter()
+    iq = make_batch(n, slot_len, seed, 1531 if long_frames else 1200, snrs)
+    res = {"frames": n, "slot_len": slot_len, "seed": seed, "snrs_db": list(snrs), "generate_s": time.perf_counter() - t0,
+           "decode_small_max": decode_small_max, "equalisers": {}}
+    threads = os.cpu_count() or 1
+    old_env = os.environ.get("WIFIRX_DECODE_SMALL_MAX")
+    if decode_small_max is not None:
+        os.environ["WIFIRX_DECODE_SMALL_MAX"] = str(decode_small_max)
+    try:
+        for ce in equalisers:
+            name = ("LS", "LMS", "COMB", "STA")[ce]
+            rx = capi.WifiRx(max_sym=max_sym, llr_bits=llr_bits, want_carrier=True, chan_est=ce)
+            r = rx.demod_batch(iq, slot_len, want_csi=True)
+            d = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=2048)
+            rx.close()
+            prm = orc.make_params(max_sym=max_sym, llr_bits=llr_bits, chan_est=ce)
+            o = orc.demod_batch(iq, slot_len, prm, want_eq=True, want_csi=True, n_threads=threads)
+            of = o["frames"].copy()
+            opsdu = orc.decode_batch(of, o["idx"], prm, psdu_stride=2048, n_threads=threads)
+            mism = {
+                "frame_records": int((r["frames"] != o["frames"]).sum()),
+                "decisions": int((r["idx"] != o["idx"]).sum()),
+                "llr_values": int((r["llr"].view(np.uint32) != o["llr"].view(np.uint32)).sum()),
+                "equalised_points": int((r["carrier"].view(np.uint64) != o["eq"].view(np.uint64)).sum()),
+                "csi_values": int((r["csi"].view(np.uint64) != o["csi"].view(np.uint64)).sum()),
+                "flags_after_decode": int((d["frames"]["flags"] != of["flags"]).sum()),
+            }
+            dec = (d["frames"]["flags"] & capi.F_DECODED) != 0
+            col = np.arange(d["psdu"].shape[1])[None, :] < d["frames"]["psdu_len"][:, None].astype(np.int64)
+            mism["psdu_bytes"] = int(((d["psdu"] != opsdu[:, :d["psdu"].shape[1]]) & col & dec[:, None]).sum())
+            fl = d["frames"]["flags"]
+            res["equalisers"][name] = {
+                "mismatches": mism,
+                "total_mismatches": int(sum(mism.values())),
+                "detected": int(((fl & capi.F_DETECTED) != 0).sum()), "signal_ok": int(((fl & capi.F_SIGNAL) != 0).sum()),
+                "complete": int(((fl & capi.F_COMPLETE) != 0).sum()), "crc_ok": int(((fl & capi.F_CRC_OK) != 0).sum()),
+                "decisions_compared": int(r["idx"].size), "llr_values_compared": int(r["llr"].size),
+            }
+    finally:
+        if decode_small_max is not None:
+            if old_env is None:
+                os.environ.pop("WIFIRX_DECODE_SMALL_MAX", None)
+            else:
+                os.environ["WIFIRX_DECODE_SMALL_MAX"] = old_env
+    res["all_bit_exact"] = all(v["total_mismatches"] == 0 for v in res["equalisers"].values())
+    res["seconds"] = time.perf_counter() - t0
+    return res
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     long_frames = len(sys.argv) > 3 and sys.argv[3] == "long"
-    slot_len, max_sym, llr_bits = (45056, 511, 1) if long_frames else (8192, 96, 6)
-    from oracle import oracle as orc
-    t0 = time.perf_counter()
-    iq = make_batch(n, slot_len, seed, 1531 if long_frames else 1200)
-    res = {"frames": n, "slot_len": slot_len, "seed": seed, "generate_s": time.perf_counter() - t0, "equalisers": {}}
-    threads = os.cpu_count() or 1
-    for ce, name in enumerate(("LS", "LMS", "COMB", "STA")):
-        rx = capi.WifiRx(max_sym=max_sym, llr_bits=llr_bits, want_carrier=True, chan_est=ce)
-        r = rx.demod_batch(iq, slot_len, want_csi=True)
-        d = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=2048)
-        rx.close()
-        prm = orc.make_params(max_sym=max_sym, llr_bits=llr_bits, chan_est=ce)
-        o = orc.demod_batch(iq, slot_len, prm, want_eq=True, want_csi=True, n_threads=threads)
-        opsdu = orc.decode_batch(o["frames"].copy(), o["idx"], prm, psdu_stride=2048, n_threads=threads)
-        of = o["frames"].copy()
-        orc.decode_batch(of, o["idx"], prm, psdu_stride=2048, n_threads=threads)
-        mism = {
-            "frame_records": int((r["frames"] != o["frames"]).sum()),
-            "decisions": int((r["idx"] != o["idx"]).sum()),
-            "llr_values": int((r["llr"].view(np.uint32) != o["llr"].view(np.uint32)).sum()),
-            "equalised_points": int((r["carrier"].view(np.uint64) != o["eq"].view(np.uint64)).sum()),
-            "csi_values": int((r["csi"].view(np.uint64) != o["csi"].view(np.uint64)).sum()),
-            "flags_after_decode": int((d["frames"]["flags"] != of["flags"]).sum()),
-        }
-        dec = np.nonzero(d["frames"]["flags"] & capi.F_DECODED)[0]
-        bad = 0
-        for k in dec:
-            L = int(d["frames"]["psdu_len"][k])
-            bad += int((d["psdu"][k, :L] != opsdu[k, :L]).sum())
-        mism["psdu_bytes"] = bad
-        fl = d["frames"]["flags"]
-        res["equalisers"][name] = {
-            "mismatches": mism,
-            "total_mismatches": int(sum(mism.values())),
-            "detected": int(((fl & capi.F_DETECTED) != 0).sum()), "signal_ok": int(((fl & capi.F_SIGNAL) != 0).sum()),
-            "complete": int(((fl & capi.F_COMPLETE) != 0).sum()), "crc_ok": int(((fl & capi.F_CRC_OK) != 0).sum()),
-        }
-    res["all_bit_exact"] = all(v["total_mismatches"] == 0 for v in res["equalisers"].values())
-    res["seconds"] = time.perf_counter() - t0
-    print(json.dumps(res))
+    print(json.dumps(run(n, seed, long_frames)))
 
 
 if __name__ == "__main__":

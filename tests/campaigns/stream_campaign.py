@@ -36,10 +36,7 @@ def make_stream(rng, n_frames):
     return x.astype(np.complex64)
 
 
-def main():
-    n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    per = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+def run(n_streams=40, per=30, seed=1):
     from oracle import oracle as orc
     rng = np.random.default_rng(seed)
     t0 = time.perf_counter()
@@ -81,7 +78,14 @@ def main():
     tot["all_equal"] = (tot["frame_count_differs"] + tot["mismatching_records"] + tot["mismatching_decisions"] +
                         tot["mismatching_psdu_bytes"]) == 0
     tot["seconds"] = time.perf_counter() - t0
-    print(json.dumps(tot))
+    return tot
+
+
+def main():
+    n_streams = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    per = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    print(json.dumps(run(n_streams, per, seed)))
 
 
 if __name__ == "__main__":
