@@ -458,7 +458,7 @@ def main():
             n_host = max(1, min(n_frames, args.host_samples // SLOT_LEN))
             xs = iq[:n_host].cpu().numpy().view(np.complex64).reshape(-1)
             blk = block.wifi_phy_rx(bandwidth=BANDWIDTH, frequency=FREQUENCY, max_sym=n_sym, publish_carrier=False,
-                                    device=local_rank)
+                                    device=local_rank, batch_samples=1 << 22)
             got = []
             grshim.msg_connect(blk, "mac_out", grshim.sink_block(got.append), "in")
             grshim.run_stream(blk, xs[:SLOT_LEN * min(n_host, 256)], chunk=8192)     # warm-up (allocations); stop() settles its frames
@@ -473,12 +473,29 @@ def main():
             t = time.perf_counter()
             grshim.run_stream(blk, xs, chunk=8192, finish=False)
             dtw = time.perf_counter() - t
+            blk.close()
+            # the reference wires the `carrier` port too (IRS_AP.py:293,312-313: frame_equalizer.symbols -> the SNR
+            # probe): one Python PDU per data SYMBOL, 50 per frame here -- on an eighth of the samples
+            blk = block.wifi_phy_rx(bandwidth=BANDWIDTH, frequency=FREQUENCY, max_sym=n_sym, publish_carrier=True,
+                                    device=local_rank, batch_samples=1 << 22)
+            got_c, n_car = [], [0]
+            grshim.msg_connect(blk, "mac_out", grshim.sink_block(got_c.append), "in")
+            grshim.msg_connect(blk, "carrier", grshim.sink_block(lambda m: n_car.__setitem__(0, n_car[0] + 1)), "in")
+            xc = xs[:SLOT_LEN * max(256, n_host // 8)]
+            grshim.run_stream(blk, xc[:SLOT_LEN * 64], chunk=8192)
+            n_car[0] = 0
+            t = time.perf_counter()
+            grshim.run_stream(blk, xc, chunk=8192)
+            dtc = time.perf_counter() - t
             result["host_path"] = {"gsamples_per_s": xs.size / dth / 1e9, "work_chunk_items": 8192, "samples": int(xs.size),
-                                   "pdus": n_pdu, "frames_in": n_host,
+                                   "pdus": n_pdu, "frames_in": n_host, "batch_samples": 1 << 22,
                                    "work_only_gsamples_per_s": xs.size / dtw / 1e9,
+                                   "with_carrier_port_gsamples_per_s": xc.size / dtc / 1e9,
+                                   "with_carrier_port": {"samples": int(xc.size), "carrier_pdus": n_car[0]},
                                    "note": "wifi_phy_rx.work() with pageable host chunks: staging copy, PCIe, detection, frame "
                                            "kernel, decode_mac, one Python PDU per frame (a frame every 4608 samples); "
-                                           "work_only = the same calls without building PDUs; never `value`"}
+                                           "work_only = the same calls without building PDUs; with_carrier_port = also one "
+                                           "Python PDU per data symbol on `carrier`, as IRS_AP.py:293 wires it; never `value`"}
             blk.close()
 
         # ---- config 2, CFO = 0 variant: same frames and noise law, no carrier offset ----

@@ -5,6 +5,7 @@
 #include <emmintrin.h>      // SSE2 streaming stores of the staging copy (x86-64 baseline)
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -93,16 +94,24 @@ struct wifirx_handle {
     bool    w_started = false, w_stop = false, w_busy = false, w_has_job = false;
     const float* w_job_ptr = nullptr;   size_t w_job_n = 0;   bool w_job_flush = false;
     int     w_rc = 0;                   std::string w_err;     // first failure of a batch, reported by the next call
+    std::string w_err_local;            // the worker's own error text (only the worker writes it; h->err belongs to the caller's thread)
+    bool    w_retry = false;            // the failed batch is still staged (its ring buffer untouched): the next push / flush re-submits it
+    const float* w_retry_ptr = nullptr; size_t w_retry_n = 0;   bool w_retry_flush = false;
     float2* ring[2] = { nullptr, nullptr };   size_t ring_cap = 0, ring_fill = 0;   int ring_cur = 0;
+    size_t  push_consumed = 0;          // wifirx_push_consumed
+    std::atomic<uint32_t> n_queued{0};  // frames waiting for wifirx_poll (wifirx_queued: read without the lock)
 };
 
 namespace {
 
 thread_local std::string g_err;
+thread_local bool t_is_worker = false;      // set by the handle's stream worker thread
 
+// h->err is written by the caller's thread only (one handle = calls serialised by the caller); the stream worker keeps
+// its text in w_err_local until the caller's next push / flush takes it over (stream_worker_take_error).
 int fail(wifirx_handle* h, int code, const std::string& msg)
 {
-    if (h) h->err = msg;
+    if (h) { if (t_is_worker) h->w_err_local = msg; else h->err = msg; }
     g_err = msg;
     return code;
 }
@@ -247,7 +256,8 @@ int wifirx_set_param(wifirx_handle* h, int id, double value)
         h->decode_small_max = (uint32_t)value;
         return WIFIRX_OK;
     case WIFIRX_P_STREAM_BATCH:
-        if (!(value >= 0) || value > 1e9) return fail(h, WIFIRX_EINVAL, "stream batch out of range");
+        // two pinned staging buffers of one batch each: at most 2^27 samples (1 GiB) per buffer
+        if (!(value >= 0) || value > (double)WIFIRX_STREAM_BATCH_MAX) return fail(h, WIFIRX_EINVAL, "stream batch out of range (0 .. WIFIRX_STREAM_BATCH_MAX)");
         h->stream_batch = (int64_t)value;
         return WIFIRX_OK;
     default:
@@ -294,6 +304,7 @@ int wifirx_dev_free(wifirx_handle* h, void* p)
 int wifirx_memcpy_h2d(wifirx_handle* h, void* dst, const void* src, size_t bytes)
 {
     if (!h) return WIFIRX_EINVAL;
+    stream_worker_wait_idle(h);
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -303,6 +314,7 @@ int wifirx_memcpy_h2d(wifirx_handle* h, void* dst, const void* src, size_t bytes
 int wifirx_memcpy_d2h(wifirx_handle* h, void* dst, const void* src, size_t bytes)
 {
     if (!h) return WIFIRX_EINVAL;
+    stream_worker_wait_idle(h);
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -353,6 +365,7 @@ static int demod_batch_impl(wifirx_handle* h, const float* iq, int iq_on_device,
     if (rc) return rc;
     if (!iq) return fail(h, WIFIRX_EINVAL, "iq is null");
     if (n_slots == 0) return WIFIRX_OK;
+    stream_worker_wait_idle(h);            // a stream batch in flight uses the handle's stream and workspaces
     HIP_TRY(h, hipSetDevice(h->device));
     const wr::DemodParams prm = params_of(h);
     const size_t n_iq = slot_off_host ? (size_t)(slot_off_host[n_slots] - slot_off_host[0]) + (size_t)slot_off_host[0]
@@ -438,6 +451,7 @@ int wifirx_time_demod(wifirx_handle* h, const float* iq_dev, uint32_t slot_len, 
     int rc = check_batch(h, slot_len, n_slots, out);
     if (rc) return rc;
     if (!iq_dev || !ms_mean || iters <= 0 || !out->on_device) return fail(h, WIFIRX_EINVAL, "device buffers and iters > 0 required");
+    stream_worker_wait_idle(h);
     HIP_TRY(h, hipSetDevice(h->device));
     const wr::DemodParams prm = params_of(h);
     struct Events {                       // destroyed on every exit
@@ -469,6 +483,7 @@ int wifirx_synth_slots(wifirx_handle* h, const float* templates, int templates_o
     if (!h || !templates || !slots) return WIFIRX_EINVAL;
     if (n_templates == 0 || frame_len == 0) return fail(h, WIFIRX_EINVAL, "empty templates");
     if (slot_len % 2) return fail(h, WIFIRX_EINVAL, "slot_len must be even");
+    stream_worker_wait_idle(h);
     HIP_TRY(h, hipSetDevice(h->device));
     const float2* d_t = reinterpret_cast<const float2*>(templates);
     void* tmp = nullptr;

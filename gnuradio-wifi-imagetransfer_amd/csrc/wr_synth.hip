@@ -51,7 +51,9 @@ void synth_kernel(const float2* __restrict__ templates, uint32_t n_templates, ui
         sincosf(6.283185307179586f * u01(r.y), &s1, &c1);
         sincosf(6.283185307179586f * u01(r.w), &s2, &c2);
         const float h = 0.70710678118654752f * noise;       // noise = 1 (unit-variance AWGN) or 0 (noiseless: tests)
-        float4 o = make_float4(h * r1 * c1, h * r1 * s1, h * r2 * c2, h * r2 * s2);
+        float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (noise != 0.0f)                                   // not 0 * r: a Box-Muller radius of inf (u01 = 0) would give NaN
+            o = make_float4(h * r1 * c1, h * r1 * s1, h * r2 * c2, h * r2 * s2);
         const float2* tp = templates + (size_t)(slot % n_templates) * frame_len;
 #pragma unroll
         for (int e = 0; e < 2; e++) {

@@ -34,7 +34,7 @@ LINKTYPE_IEEE802_11 = 105
 
 class wifi_phy_rx(grshim.sync_block):
     def __init__(self, bandwidth=10e6, chan_est=LS, encoding=0, frequency=5.89e9, sensitivity=0.56,
-                 max_sym=511, publish_carrier=True, device=0, batch_samples=1 << 22, publish_csi=False, snr_probe=None):
+                 max_sym=511, publish_carrier=True, device=0, batch_samples=None, publish_csi=False, snr_probe=None):
         grshim.sync_block.__init__(self, name="wifi_phy_rx", in_sig=[np.complex64], out_sig=None)
         self.bandwidth = float(bandwidth)
         self.chan_est = int(chan_est)
@@ -56,19 +56,28 @@ class wifi_phy_rx(grshim.sync_block):
                                chan_est=self.chan_est, max_sym=max_sym, llr_bits=0,
                                want_carrier=self.publish_carrier, device=device)
         # The scheduler calls work() with a few thousand items.  The library copies them into a pinned staging buffer
-        # and returns; once `batch_samples` have come in (about 0.2 s of signal at 20 MS/s) its worker thread runs the
-        # device pipeline for that batch while work() keeps filling the next one -- one device round trip per work()
-        # call could not keep up.  Finished frames are fetched once per batch, and at stop().
-        self.batch_samples = int(batch_samples)
+        # and returns; once `batch_samples` have come in its worker thread runs the device pipeline for that batch while
+        # work() keeps filling the next one -- one device round trip per work() call could not keep up.  Default: 50 ms
+        # of signal at the block's bandwidth (2^16 samples at least), so that a PDU leaves `mac_out` about 50-100 ms
+        # after its last sample arrived (the reference's decode_mac publishes per frame; INTEGRATION.md, "Latency"); a
+        # file-driven run that only cares for throughput passes a larger value (bench.py: 2^22).  Finished frames are
+        # published by the first work() call after their batch is through (wifirx_queued: one atomic load per call), and
+        # at stop().
+        if batch_samples is None:
+            batch_samples = max(1 << 16, int(0.05 * self.bandwidth))
+        self.batch_samples = min(int(batch_samples), capi.STREAM_BATCH_MAX)
         self._rx.set_param(capi.P_STREAM_BATCH, self.batch_samples)
         self._rx.set_param(capi.P_STREAM_IDX, 0)            # PDUs only: the hard decisions stay on the device
         self._push = capi.lib().wifirx_push
+        self._queued = capi.lib().wifirx_queued
         self._h = self._rx._h
-        self._since_poll = 0
         self._p_mac = grshim.intern("mac_out")
         self._p_car = grshim.intern("carrier")
         self.frames_ok = 0
         self.frames_dropped = 0
+        self.raise_on_error = True
+        self.push_errors = 0
+        self.last_error = ""
 
     # ---- setters generated for the hier block's parameters (gnu_radio/IRS_user.py:229,265,273;
     #      equaliser setters at gnu_radio/IRS_AP.py:348,373,382) ----
@@ -121,17 +130,22 @@ class wifi_phy_rx(grshim.sync_block):
                 buf = x.ctypes.data
             rc = self._push(self._h, buf, n, 0)              # copies; x is the scheduler's again
             if rc:
-                self._rx._check(rc)
-            self._since_poll += n
-            if self._since_poll >= self.batch_samples:
-                self._since_poll = 0
+                # Nothing is lost or doubled: what the library took over (usually nothing) counts as consumed, the
+                # scheduler hands the rest in again with the next call (include/wifirx.h, WIFIRX_P_STREAM_BATCH: ERRORS).
+                # raise_on_error (default): the error surfaces as an exception of the block, as any failing GNU Radio
+                # block's would; otherwise it is counted and work() reports the consumed items.
+                self.push_errors += 1
+                self.last_error = capi.lib().wifirx_last_error(self._h).decode()
+                if self.raise_on_error:
+                    self._rx._check(rc)
+                n = self._rx.push_consumed()
+            if self._queued(self._h):
                 self._publish()
         return n
 
     def stop(self):
         """End of stream: settle the frames still waiting for samples."""
         self._rx._check(self._push(self._h, None, 0, 0))
-        self._since_poll = 0
         self._publish()
         return True
 

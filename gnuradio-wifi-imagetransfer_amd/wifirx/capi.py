@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("WIFIRX_LIB") or os.path.join(_HERE, "libwifirx.so")  
 ABI_VERSION = 4
 DECODE_INPUT = "planes"      # what demod_batch(decode=True) hands decode_mac: "planes" (wifirx_out.hbits) or "idx"
 EQ_LS, EQ_LMS, EQ_COMB, EQ_STA = 0, 1, 2, 3
+STREAM_BATCH_MAX = 1 << 27          # WIFIRX_STREAM_BATCH_MAX
 P_BANDWIDTH, P_FREQUENCY, P_SENSITIVITY, P_CHAN_EST, P_STREAM_BATCH, P_DECODE_SMALL_MAX, P_LLR_CSI, P_STREAM_IDX = 1, 2, 3, 4, 5, 6, 7, 8
 F_DETECTED, F_SYNC, F_SIGNAL, F_COMPLETE, F_LLR, F_DECODED, F_CRC_OK = 1, 2, 4, 8, 16, 32, 64
 
@@ -33,6 +34,7 @@ EXPORTS = [
     "wifirx_get_stats", "wifirx_demod_batch", "wifirx_decode_batch", "wifirx_push", "wifirx_poll", "wifirx_poll_csi",
     "wifirx_sync", "wifirx_stream", "wifirx_synth_slots", "wifirx_dev_alloc", "wifirx_dev_free",
     "wifirx_memcpy_h2d", "wifirx_memcpy_d2h", "wifirx_time_demod", "wifirx_poll_ex", "wifirx_demod_batch_v",
+    "wifirx_push_consumed", "wifirx_queued",
 ]
 
 
@@ -82,6 +84,10 @@ _lib.wifirx_demod_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32,
 _lib.wifirx_decode_batch.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Out)]
 _lib.wifirx_demod_batch_v.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(Out)]
 _lib.wifirx_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+_lib.wifirx_push_consumed.restype = C.c_size_t
+_lib.wifirx_queued.restype = C.c_uint32
+_lib.wifirx_queued.argtypes = [C.c_void_p]
+_lib.wifirx_push_consumed.argtypes = [C.c_void_p]
 _lib.wifirx_poll.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                              C.c_uint32, C.POINTER(C.c_uint32)]
 _lib.wifirx_poll_csi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -310,6 +316,17 @@ class WifiRx:
     def push(self, iq: np.ndarray):
         iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
         self._check(_lib.wifirx_push(self._h, _np_ptr(iq), iq.size, 0))
+
+    def flush(self):
+        self._check(_lib.wifirx_push(self._h, None, 0, 0))
+
+    def queued(self) -> int:
+        """finished frames waiting for poll()"""
+        return int(_lib.wifirx_queued(self._h))
+
+    def push_consumed(self) -> int:
+        """Leading samples of the last push() the stream has taken over (after an error: where to repeat it from)."""
+        return int(_lib.wifirx_push_consumed(self._h))
 
     def poll(self, cap=256, psdu_stride=2048, want_idx=False, want_csi=False, want_stats=False, trim_psdu=False):
         """Finished frames of the stream, oldest first (at most `cap`).  The landing buffers are kept between calls

@@ -96,11 +96,15 @@ def run_stream(block, samples: np.ndarray, chunk: int = 8192, finish: bool = Tru
     """Drive ``block.work()`` the way the GNU Radio scheduler would: successive chunks of the input
     stream, each call consuming what ``work`` returns."""
     samples = np.ascontiguousarray(samples, dtype=np.complex64)
-    pos = 0
+    pos = stalls = 0
     while pos < samples.size:
         n = block.work([samples[pos:pos + chunk]], [])
-        if n <= 0:
-            break
+        if n <= 0:                      # nothing consumed: the scheduler calls again; give up after a few in a row
+            stalls += 1
+            if stalls > 8:
+                break
+            continue
+        stalls = 0
         pos += n
     if finish and hasattr(block, "stop"):
         block.stop()

@@ -13,7 +13,9 @@
  * on a handle.  One handle = one stream of samples = one HIP stream; calls on one handle must be
  * serialised by the caller, different handles are independent (GNU Radio runs each block on its
  * own thread, so this matches the reference's threading).  Stream mode with WIFIRX_P_STREAM_BATCH runs its
- * device pipeline on a worker thread owned by the handle; that is internal and changes nothing of the above.
+ * device pipeline on a worker thread owned by the handle: wifirx_push returns while a batch is still in flight.
+ * That stays internal: every other entry point of the handle (batch calls, decode, set_param, sync, memcpy) first
+ * waits for the batch in flight, and wifirx_last_error only ever shows text written on the caller's thread.
  *
  * There is NO CPU fallback in this library: wifirx_create() fails with WIFIRX_ENODEV when no
  * gfx950 device is usable.  The CPU restatement lives in oracle/ and is test infrastructure only.
@@ -113,8 +115,18 @@ typedef struct wifirx_config {
 #define WIFIRX_P_CHAN_EST    4
 /* stream mode: wifirx_push only collects samples until this many are waiting, then detects / demodulates /
  * decodes them in one go (0 = on every push).  A GNU Radio scheduler hands work() a few thousand items at a
- * time; one GPU round trip per such call would not keep up with the sample rate.  A push with n = 0 flushes. */
+ * time; one GPU round trip per such call would not keep up with the sample rate.  A push with n = 0 flushes.
+ * At most WIFIRX_STREAM_BATCH_MAX (two pinned host buffers of one batch each are kept).  Changing the value while
+ * samples are staged first runs those samples as a (short) batch.
+ * ERRORS: the stream never gains a gap or a doubled sample through a failed push.  wifirx_push_consumed() tells how
+ * many leading samples of the last wifirx_push call the stream has taken over: all of them after WIFIRX_OK; after an
+ * error 0 -- repeat the call as it was (an allocation may succeed now) --, except for a call that spanned several
+ * batches (n > batch size), which may have taken a prefix: repeat it from there.  Without a batch size a failed pass
+ * is undone as a whole.  With one, the failure of a batch on the worker thread is reported by the NEXT push / flush
+ * (once, before it takes anything); the failed batch stays staged in the library and the call after that runs it
+ * again before going on. */
 #define WIFIRX_P_STREAM_BATCH 5
+#define WIFIRX_STREAM_BATCH_MAX (1u << 27)
 /* decode_mac has two kernels with identical results: 128 frames per wave (throughput; a lone wave needs ~4 ms)
  * and one frame per wave (latency; ~0.2 ms per frame).  Batches of up to this many frames take the second one
  * (default 16384; 0 = always the first). */
@@ -228,12 +240,21 @@ int  wifirx_decode_batch(wifirx_handle* h, uint32_t n_slots, const wifirx_out* o
  * samples seen so far are demodulated + decoded and queued for wifirx_poll. */
 int  wifirx_push(wifirx_handle* h, const float* iq, size_t n, int iq_on_device);
 
+/* How many leading samples of the last wifirx_push call the stream has taken over: n after WIFIRX_OK; after an error
+ * the count from which the caller repeats the call (0 unless the call spanned several batches).  See
+ * WIFIRX_P_STREAM_BATCH, ERRORS.  GNU Radio equivalent: what work() would pass to consume_each() on an error path. */
+size_t wifirx_push_consumed(const wifirx_handle* h);
+
 /* Fetch up to `cap` queued frames (host memory).  For frame i: record frames[i], its PSDU at
  * psdu + i*psdu_stride, and -- when requested at create time and the pointers are non-NULL --
  * its hard decisions at idx + i*max_sym*48 and equalised points at carrier + i*max_sym*96 floats.
  * *n_out receives the number of frames written. */
 int  wifirx_poll(wifirx_handle* h, wifirx_frame* frames, uint8_t* psdu, uint32_t psdu_stride,
                  uint8_t* idx, float* carrier, uint32_t cap, uint32_t* n_out);
+
+/* Number of finished frames waiting for wifirx_poll*: one atomic load, no lock -- cheap enough for every work() call
+ * (the block polls only when this is non-zero). */
+uint32_t wifirx_queued(const wifirx_handle* h);
 
 /* wifirx_poll that also delivers the channel state of every frame: csi + i*104 floats = the LS estimate on the 52
  * occupied sub-carriers (re, im), the `csi` entry upstream's frame_equalizer puts into the frame's tag dictionary

@@ -175,10 +175,11 @@ def test_push_after_a_failed_allocation_recovers(orc, monkeypatch):
             except capi.WifiRxError as e:
                 assert e.code == -3 or "hipMalloc" in str(e)          # WIFIRX_ENOMEM
                 failures += 1
-                # a failure of the sample-side buffers comes before the copy: nothing was consumed, hand the piece in
-                # again; a failure of the output rows comes after it: the triggers stay pending for the next push
-                if "stream buffers" in str(e):
-                    rx.push(piece)
+                # a failed pass is undone as a whole: nothing was consumed, whichever allocation it was -- hand the
+                # piece in again (include/wifirx.h, WIFIRX_P_STREAM_BATCH: ERRORS)
+                assert rx.push_consumed() == 0
+                rx.push(piece)
+                assert rx.push_consumed() == piece.size
             got.append(rx.poll(cap=64, want_idx=True))
         rx._check(capi.lib().wifirx_push(rx._h, None, 0, 0))
         got.append(rx.poll(cap=64, want_idx=True))
@@ -188,3 +189,162 @@ def test_push_after_a_failed_allocation_recovers(orc, monkeypatch):
         assert np.array_equal(frames, ref_frames), k
         assert np.array_equal(psdu, ref_psdu), k
     assert failures >= 8
+
+
+def _ref_frames(x, chunk=30000):
+    from wifirx import capi
+    rx = capi.WifiRx(max_sym=511)
+    ref = []
+    for p in range(0, x.size, chunk):
+        rx.push(x[p:p + chunk])
+        ref.append(rx.poll(cap=64, want_idx=True))
+    rx.flush()
+    ref.append(rx.poll(cap=64, want_idx=True))
+    rx.close()
+    return np.concatenate([g["frames"] for g in ref]), np.concatenate([g["psdu"] for g in ref])
+
+
+@pytest.mark.parametrize("batch,chunk", [(20000, 777), (50000, 8192), (20000, 70000)])
+def test_worker_batch_failure_loses_nothing(monkeypatch, batch, chunk):
+    """The same allocation failures with a batch size set, i.e. on the handle's WORKER thread (the block's default mode):
+    the failure is reported by a later push, which has consumed what wifirx_push_consumed says (nothing, unless the call
+    spanned several batches); the failed batch stays staged in the library and runs again.  A caller that repeats the
+    reported call from there gets exactly the frames of an undisturbed run -- no gap, no doubled sample."""
+    from wifirx import capi
+    x, _ = build_stream(seed=5)
+    ref_frames, ref_psdu = _ref_frames(x)
+    assert len(ref_frames) == 10
+    failures = 0
+    for k in range(1, 14):
+        monkeypatch.setenv("WIFIRX_TEST_FAIL_ALLOC", str(k))
+        rx = capi.WifiRx(max_sym=511)
+        rx.set_param(capi.P_STREAM_BATCH, batch)
+        got = []
+        p = 0
+        while p < x.size:
+            piece = x[p:p + chunk]
+            try:
+                rx.push(piece)
+                p += piece.size
+            except capi.WifiRxError as e:
+                assert e.code == -3, str(e)
+                failures += 1
+                p += rx.push_consumed()               # repeat from where the library stopped taking samples
+            got.append(rx.poll(cap=64, want_idx=True))
+        for attempt in range(3):                      # a flush can report a failed batch too: flush again
+            try:
+                rx.flush()
+                break
+            except capi.WifiRxError as e:
+                assert e.code == -3, str(e)
+                failures += 1
+        got.append(rx.poll(cap=64, want_idx=True))
+        st = rx.stats()
+        rx.close()
+        frames = np.concatenate([g["frames"] for g in got])
+        psdu = np.concatenate([g["psdu"] for g in got])
+        assert np.array_equal(frames, ref_frames), k
+        assert np.array_equal(psdu, ref_psdu), k
+        assert st["samples_in"] == x.size, (k, st)
+    assert failures >= 8
+
+
+def test_block_survives_a_failed_batch(monkeypatch):
+    """... and through wifi_phy_rx: with raise_on_error off work() reports what was consumed, the scheduler hands the
+    rest in again, every PDU arrives once; with it on (default) the failure is an exception of the block."""
+    from wifirx import block, capi, grshim
+    x, psdus = build_stream(seed=5)
+    for k in (1, 2, 4, 6, 9):
+        monkeypatch.setenv("WIFIRX_TEST_FAIL_ALLOC", str(k))
+        blk = block.wifi_phy_rx(bandwidth=20e6, publish_carrier=False, batch_samples=20000)
+        blk.raise_on_error = False
+        got = []
+        grshim.msg_connect(blk, "mac_out", grshim.sink_block(got.append), "in")
+        pos = grshim.run_stream(blk, x, chunk=4096, finish=False)
+        assert pos == x.size
+        for attempt in range(3):
+            try:
+                blk.stop()
+                break
+            except capi.WifiRxError:
+                pass
+        assert blk.push_errors >= 1 and "hipMalloc" in blk.last_error, (k, blk.push_errors, blk.last_error)
+        assert len(got) == len(psdus), (k, len(got))
+        for (meta, blob), want in zip(got, psdus):
+            assert np.array_equal(np.asarray(blob), want[:-4])
+        blk.close()
+    monkeypatch.setenv("WIFIRX_TEST_FAIL_ALLOC", "1")
+    blk = block.wifi_phy_rx(bandwidth=20e6, publish_carrier=False, batch_samples=20000)
+    with pytest.raises(capi.WifiRxError):
+        grshim.run_stream(blk, x, chunk=4096)
+    blk.close()
+
+
+def test_batch_size_change_with_samples_staged_is_no_dead_end(orc):
+    """WIFIRX_P_STREAM_BATCH changed while samples sit in the staging buffer (round 2: every later push, the flush
+    included, returned EINVAL): the staged samples run as a short batch, the stream goes on, same frames as the oracle."""
+    from wifirx import capi
+    x, _ = build_stream(seed=7)
+    o, opsdu = oracle_stream(orc, x)
+    rx = capi.WifiRx(max_sym=511)
+    got = []
+    sizes = [50000, 20000, 0, 120000, 30000]
+    p, i = 0, 0
+    while p < x.size:
+        rx.set_param(capi.P_STREAM_BATCH, sizes[i % len(sizes)])
+        i += 1
+        for _ in range(3):
+            rx.push(x[p:p + 7000])
+            p += 7000
+        got.append(rx.poll(cap=64, want_idx=True))
+    rx.set_param(capi.P_STREAM_BATCH, 4096)
+    rx.flush()
+    got.append(rx.poll(cap=64, want_idx=True))
+    rx.close()
+    frames = np.concatenate([g["frames"] for g in got])
+    assert np.array_equal(frames, o["frames"])
+    with pytest.raises(capi.WifiRxError):
+        rx2 = capi.WifiRx(max_sym=64)
+        try:
+            rx2.set_param(capi.P_STREAM_BATCH, capi.STREAM_BATCH_MAX + 1)
+        finally:
+            rx2.close()
+
+
+def test_batch_calls_interleaved_with_a_stream_batch_in_flight(orc):
+    """Batch-mode entry points on a handle whose stream worker has a batch in flight: they wait for it; both
+    the stream's frames and the batch results equal the oracle's.  Repeated so that the calls do meet a busy worker."""
+    from wifirx import capi
+    from helpers import make_slots
+    x, _ = build_stream(seed=9)
+    o, opsdu = oracle_stream(orc, x)
+    iq, slot_len, tx = make_slots(96, 5, psdu_len=200, snr_db=24.0, seed=3)
+    prm = orc.make_params(max_sym=tx.n_sym, llr_bits=0)
+    ob = orc.demod_batch(iq, slot_len, prm)
+    obp = orc.decode_batch(ob["frames"], ob["idx"], prm, psdu_stride=512)
+    rx = capi.WifiRx(max_sym=511)
+    rx.set_param(capi.P_STREAM_BATCH, 16384)
+    for rep in range(4):
+        got = []
+        for p in range(0, x.size, 16384):
+            rx.push(x[p:p + 16384])                   # hands a full batch to the worker and returns
+            rb = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=512)
+            assert np.array_equal(rb["frames"], ob["frames"]), (rep, p)
+            assert np.array_equal(rb["psdu"][:, :200], obp[:, :200])
+            got.append(rx.poll(cap=64, want_idx=True))
+        rx.flush()
+        got.append(rx.poll(cap=64, want_idx=True))
+        frames = np.concatenate([g["frames"] for g in got])
+        psdu = np.concatenate([g["psdu"] for g in got])
+        assert len(frames) == len(o["frames"])
+        want = o["frames"]
+        if rep == 0:
+            assert np.array_equal(frames, want)
+        # a further pass over the same samples continues the stream (trigger positions move on, the 16-sample blocks of
+        # the window sums sit elsewhere): same frames, same bytes
+        assert np.array_equal(frames["flags"], want["flags"]) and np.array_equal(frames["psdu_len"], want["psdu_len"])
+        for i in range(len(frames)):
+            L = int(frames["psdu_len"][i])
+            if frames["flags"][i] & capi.F_CRC_OK:
+                assert np.array_equal(psdu[i, :L], opsdu[i, :L])
+    rx.close()
