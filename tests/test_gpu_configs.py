@@ -23,8 +23,10 @@ CFO_20PPM = 2 * np.pi * 20e-6 * 5.89e9 / 20e6
 @pytest.mark.timeout(900)
 def test_config3_reduced_ber_sweep(orc):
     """SNR 5, 10, ..., 30 dB x 2048 frames: the GPU's frame records and hard decisions equal the oracle's at every
-    point; coded-bit BER falls monotonically and sits within a confidence interval of the 100 000-frame table
-    (tests/golden/config3_ber_table.json, made on an MI355X in round 1)."""
+    point; coded-bit BER falls monotonically, and BER, FER and detection rate sit within a confidence interval of
+    tests/golden/config3_ber_table.json -- made by the ORACLE on the CPU from host-generated frames
+    (tools/make_config3_ber_table.py, 30 000 frames per point; no GPU output in it), so these asserts are oracle parity
+    too, on independent noise."""
     from wifirx import capi
     table = {p["snr_db"]: p for p in json.load(open(os.path.join(GOLD, "config3_ber_table.json")))["points"]}
     taps = np.load(os.path.join(GOLD, "sv_taps.npy"))
@@ -59,8 +61,9 @@ def test_config3_reduced_ber_sweep(orc):
         per_frame = (bits_rx != bits_tx[tmpl[good]]).reshape(int(good.sum()), -1).mean(axis=1)
         ber, se = float(per_frame.mean()), float(per_frame.std() / np.sqrt(len(per_frame)))
         ref = table[snr]
-        # 5 standard errors of this sample + 2 % of the table value (the table has its own, smaller, error)
-        assert abs(ber - ref["coded_ber"]) < 5 * se + 0.02 * ref["coded_ber"], (snr, ber, ref["coded_ber"], se)
+        # 5 standard errors of the difference (this sample's and the table's) + 1 % of the table value
+        se_d = float(np.hypot(se, ref.get("coded_ber_se", 0.0)))
+        assert abs(ber - ref["coded_ber"]) < 5 * se_d + 0.01 * ref["coded_ber"], (snr, ber, ref["coded_ber"], se_d)
         assert abs(good.mean() - ref["detected_and_signal_ok"]) < 0.05
         ok = ((r["frames"]["flags"] & capi.F_CRC_OK) != 0) & (r["psdu"][:, :294] == psdu[tmpl]).all(axis=1)
         fer = 1.0 - ok.mean()
