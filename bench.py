@@ -336,12 +336,21 @@ def main():
         # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate passes, FETCH_SIZE x2 per MI355X_MICROARCH.md and tools/calib_fetch.hip): collected by
         # tools/pmc.sh, committed as profiles/*_traffic.json -- a bench run cannot count PMCs itself
+        # Both files carry the hash of the kernel sources they were measured on (tools/csrc_sha.py): a figure from other
+        # kernels than the ones that just ran is reported as stale and left out of the derived fractions.
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from csrc_sha import csrc_sha
+        sha_now = csrc_sha()
         tj = latest_profile("_traffic.json")
+        traffic_stale = bool(tj) and tj.get("csrc_sha") != sha_now
         moved_per_frame = tj["hbm_bytes_per_frame"] if tj else None
         traffic = moved_per_frame * n_frames / 1e9 if tj else None
         floor = latest_profile("_mem_floor.json")
+        floor_stale = bool(floor) and floor.get("csrc_sha") != sha_now
+        if floor_stale:
+            floor = None
         achieved = bpf * n_frames / (kernel_ms_avg * 1e-3)
-        moved = moved_per_frame * n_frames / (kernel_ms_avg * 1e-3) if tj else None
+        moved = moved_per_frame * n_frames / (kernel_ms_avg * 1e-3) if tj and not traffic_stale else None
         result = {
             "metric": "OFDM demod throughput (complex samples/s), 802.11a RX chain sync->LLR",
             "value": value,
@@ -381,6 +390,10 @@ def main():
                 "frac": achieved / HBM_PEAK,
                 "traffic": traffic,
                 "traffic_unit": "GB per launch (PMC, %s)" % (tj["_file"] if tj else "none"),
+                "traffic_stale": traffic_stale,       # true: the PMC file was measured on other kernel sources than this tree's
+                "csrc_sha": sha_now,
+                "hw_floor_ms": (moved_per_frame * n_frames / HBM_ACHIEVABLE * 1e3) if tj and not traffic_stale else None,
+                "mem_floor_stale": floor_stale,
                 "kernel": "wr::demod_batch_kernel",
                 "kernel_ms": kernel_ms_avg,
                 "algorithmic_bytes_per_frame": bpf,

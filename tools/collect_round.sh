@@ -16,6 +16,9 @@ if [ "$PART" = 1 ]; then
   tools/pmc.sh $TAG --pdu-steps 1 --steps 4 --warmup 1 > $OUT/pmc.txt 2>&1 || { tail -5 $OUT/pmc.txt; exit 1; }
   echo "pmc done"
   ./tools/mem_floor.bin > $OUT/mem_floor.txt 2>&1; tail -1 $OUT/mem_floor.txt
+  # the two files bench.py quotes, stamped with the hash of the kernel sources they were measured on (tools/csrc_sha.py)
+  grep '^{' $OUT/mem_floor.txt | tail -1 > $OUT/mem_floor.json && python3 tools/csrc_sha.py --stamp $OUT/mem_floor.json > /dev/null
+  python3 tools/pmc_to_profiles.py gpurun_out/pmc_$TAG $OUT/final > /dev/null && ls $OUT/final_*
 fi
 if [ "$PART" = 2 ]; then
   python tools/other_configs.py > $OUT/other_geometries.json 2> $OUT/other.err || tail -3 $OUT/other.err

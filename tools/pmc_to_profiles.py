@@ -11,7 +11,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_sha import csrc_sha  # noqa: E402
 
 
 def main():
@@ -36,6 +40,7 @@ def main():
     corr = 2.0
     rd, wr = d["FETCH_SIZE"] * 1024 * corr, d["WRITE_SIZE"] * 1024
     traffic = {
+        "csrc_sha": csrc_sha(),       # the kernels these counters were taken from (bench.py: traffic_stale when the tree differs)
         "kernel": dom,
         "frames_per_launch": frames,
         "FETCH_SIZE_KB": d["FETCH_SIZE"],
