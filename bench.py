@@ -111,6 +111,33 @@ def latest_profile(suffix):
         return None
 
 
+def collective_info(dist, torch, backend, rank, local_rank, world, coll_dev):
+    """What a reader of the JSON line needs to check that the collective library really saw N ranks: the backend as
+    torch.distributed reports it, the RCCL version (torch.cuda.nccl.version(): RCCL on ROCm), the rank count as a
+    collective itself counts it (all-reduce of ones), and which host / device every rank ran on."""
+    if world <= 1:
+        return None
+    ones = torch.ones(1, dtype=torch.int64, device=coll_dev)
+    dist.all_reduce(ones)
+    me = {"rank": rank, "host": socket.gethostname(), "local_rank": local_rank, "pid": os.getpid()}
+    if coll_dev == "cuda":
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            me["device"] = "%s [%s]" % (pr.name, getattr(pr, "pci_bus_id", "?"))
+        except Exception:
+            pass
+    hosts = [None] * world
+    dist.all_gather_object(hosts, me)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:
+            ver = "unavailable: %s" % e
+    return {"backend": dist.get_backend(), "rccl_version": ver, "world_size_seen": int(ones.item()),
+            "dist_world_size": dist.get_world_size(), "ranks_hosts": hosts}
+
+
 def main():
     args = parse_args()
     stub = os.environ.get("WIFIRX_BENCH_STUB") == "1"        # CPU rehearsal of the launcher + all-gather plumbing (tests/)
@@ -265,6 +292,8 @@ def main():
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
 
+    coll = collective_info(dist, torch, backend, rank, local_rank, world, coll_dev)
+
     # ---- the leg behind the hot path: decode_mac (+ RCCL all-gather of the PDUs), timed on its own ----
     pdu_leg = None
     if args.pdu_steps > 0:
@@ -380,6 +409,7 @@ def main():
             "frames_complete": n_complete,
             "frames_crc_ok": n_crc,
             "per_rank": per_rank,
+            "collective": coll,
             "n1_equivalent_gsamples_per_s": per_rank[0]["gsamples_per_s"],
             "pdu_leg": pdu_leg,
             "roofline": {
@@ -565,6 +595,7 @@ def run_stub(args, rank, world, dist, wdist, torch):
         elapsed = float(tmax.item())
     ok = True
     n_pdus = n_frames
+    coll = collective_info(dist, torch, "gloo", rank, int(os.environ.get("LOCAL_RANK", "0")), world, "cpu")
     if gather is not None:
         p_t = torch.from_numpy(psdu)
         f_t = torch.from_numpy(frames.view(np.uint8).reshape(n_frames, 32))
@@ -584,7 +615,7 @@ def run_stub(args, rank, world, dist, wdist, torch):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
                           "config": {"workload": "stub", "parallelism": "gloo, %d ranks" % world},
-                          "pdus_gathered": n_pdus, "gather_consistent": bool(ok),
+                          "pdus_gathered": n_pdus, "gather_consistent": bool(ok), "collective": coll,
                           "gather_chunks": gather.n_chunks if gather else None}))
     if world > 1:
         dist.barrier()

@@ -87,6 +87,28 @@ class sink_block(basic_block if not HAVE_GNURADIO else object):
         self.set_msg_handler(intern("in"), lambda msg: fn(to_python(msg)))
 
 
+class pmt_shim:
+    """The handful of ``pmt`` functions the reference's Python blocks and INTEGRATION.md's stub call, over plain Python
+    values -- ``pmt.to_python`` of the real thing yields the same objects.  tests/test_integration_stub.py installs it
+    (and :class:`gr_shim`) as ``sys.modules['pmt']`` / ``['gnuradio']`` to execute the documented binding."""
+    PMT_NIL = None
+    intern = staticmethod(lambda name: name)
+    cons = staticmethod(lambda a, b: (a, b))
+    make_dict = staticmethod(dict)
+    to_pmt = staticmethod(lambda v: v.copy() if isinstance(v, np.ndarray) else v)     # the real one copies into a PMT vector
+    to_python = staticmethod(lambda v: v)
+    car = staticmethod(lambda p: p[0])
+    cdr = staticmethod(lambda p: p[1])
+    init_u8vector = staticmethod(lambda n, items: np.asarray(items, dtype=np.uint8)[:n])
+    u8vector_elements = staticmethod(lambda v: list(np.asarray(v, dtype=np.uint8)))
+
+
+class gr_shim:
+    """``from gnuradio import gr`` for the shim: the two block classes."""
+    sync_block = sync_block
+    basic_block = basic_block
+
+
 def msg_connect(src, sport, dst, dport):
     """``tb.msg_connect((src, sport), (dst, dport))`` for shim blocks."""
     src._out_ports[sport].append((dst, dport))

@@ -87,6 +87,10 @@ def test_bench_launches_its_own_ranks_world2():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["data"] == "stub"
     assert j["gather_consistent"] is True and j["pdus_gathered"] == 2000 and j["gather_chunks"] == 3
+    # the fields a later SCALE run is checked by: the collective library saw both ranks
+    c = j["collective"]
+    assert c["backend"] == "gloo" and c["world_size_seen"] == 2 and c["dist_world_size"] == 2
+    assert sorted(h["rank"] for h in c["ranks_hosts"]) == [0, 1] and len({h["pid"] for h in c["ranks_hosts"]}) == 2
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
@@ -103,10 +107,8 @@ def test_chunked_gather_row_order():
     """frame_order() maps (rank, local frame) to its row of the [chunk][rank][frame] buffers, for even and ragged chunks"""
     class G(wdist.ChunkedPduGather):
         def __init__(self, n_local, n_chunks, world):       # layout arithmetic only: no process group
-            self.world, self.n_local = world, n_local
-            self.n_chunks = max(1, min(n_chunks, n_local))
-            self.cf = (n_local + self.n_chunks - 1) // self.n_chunks
-            self.n_chunks = (n_local + self.cf - 1) // self.cf
+            self.world = world
+            self._layout(n_local, n_chunks)
     for n_local, n_chunks, world in ((12, 3, 2), (11, 3, 2), (1000, 7, 8), (5, 8, 3)):
         g = G(n_local, n_chunks, world)
         o = g.frame_order()
