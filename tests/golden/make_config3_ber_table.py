@@ -5,7 +5,7 @@ PSDU 294 B (11 symbols), the 8-tap channel built from the reference's utils/SV_c
 5.89 GHz at 20 MHz, SNR 5, 10, ..., 30 dB.  Frames come from wifirx/txgen.py (NumPy transmitter + the reference's
 loop-back channel law, gnu_radio/IRS_tranceiver.py:282-294), the receiver is oracle/wifirx_oracle.c in SPEC mode.
 
-    python tools/make_config3_ber_table.py [frames_per_point=30000]
+    python tests/golden/make_config3_ber_table.py [frames_per_point=30000]
 
 The GPU test (tests/test_gpu_configs.py::test_config3_reduced_ber_sweep) draws its own noise on the device and must
 land within a confidence interval of this table: then its BER / FER asserts are oracle parity, not a comparison of the
@@ -17,7 +17,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "gnuradio-wifi-imagetransfer_amd"))
 sys.path.insert(0, ROOT)
 from wifirx import txgen  # noqa: E402  (pure NumPy; nothing of the HIP library is called here)
@@ -54,7 +54,7 @@ def main():
                        "coded_ber": float(per_frame.mean()), "coded_ber_se": float(per_frame.std() / np.sqrt(len(per_frame))),
                        "fer": float(1.0 - ok.mean())})
         print(points[-1], file=sys.stderr)
-    out = {"provenance": "tools/make_config3_ber_table.py %d: the ORACLE (oracle/wifirx_oracle.c, SPEC mode) on the CPU over frames "
+    out = {"provenance": "tests/golden/make_config3_ber_table.py %d: the ORACLE (oracle/wifirx_oracle.c, SPEC mode) on the CPU over frames "
                          "of wifirx/txgen.py -- 64-QAM 3/4, PSDU 294 B, tests/golden/sv_taps.npy, LS equaliser, CFO uniform in "
                          "+-20 ppm, NumPy noise; no GPU output is part of this table (round 1's GPU-made table: "
                          "config3_ber_table_gpu_r01.json)" % n,

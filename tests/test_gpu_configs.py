@@ -25,7 +25,7 @@ def test_config3_reduced_ber_sweep(orc):
     """SNR 5, 10, ..., 30 dB x 2048 frames: the GPU's frame records and hard decisions equal the oracle's at every
     point; coded-bit BER falls monotonically, and BER, FER and detection rate sit within a confidence interval of
     tests/golden/config3_ber_table.json -- made by the ORACLE on the CPU from host-generated frames
-    (tools/make_config3_ber_table.py, 30 000 frames per point; no GPU output in it), so these asserts are oracle parity
+    (tests/golden/make_config3_ber_table.py, 30 000 frames per point; no GPU output in it), so these asserts are oracle parity
     too, on independent noise."""
     from wifirx import capi
     table = {p["snr_db"]: p for p in json.load(open(os.path.join(GOLD, "config3_ber_table.json")))["points"]}
