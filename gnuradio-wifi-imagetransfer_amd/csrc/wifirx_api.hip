@@ -328,6 +328,7 @@ static int check_batch(wifirx_handle* h, uint32_t slot_len, uint32_t n_slots, co
     if (!h || !out) return WIFIRX_EINVAL;
     if (!out->frames) return fail(h, WIFIRX_EINVAL, "out->frames is required");
     if (slot_len == 0) return fail(h, WIFIRX_EINVAL, "slot_len must be > 0");
+    if (slot_len > 0x7fffffffu) return fail(h, WIFIRX_ERANGE, "slot longer than 2^31 - 1 samples");
     if (h->cfg.max_batch && n_slots > h->cfg.max_batch) return fail(h, WIFIRX_ERANGE, "n_slots exceeds max_batch");
     if (h->cfg.max_slot_len && slot_len > h->cfg.max_slot_len) return fail(h, WIFIRX_ERANGE, "slot_len exceeds max_slot_len");
     if (out->llr && h->cfg.llr_bits == 0) return fail(h, WIFIRX_EINVAL, "llr requested but llr_bits == 0");

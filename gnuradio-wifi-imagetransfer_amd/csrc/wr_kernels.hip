@@ -103,51 +103,104 @@ __device__ __forceinline__ uint64_t plateau_hits(uint64_t mask, uint64_t prev_ma
     return hit;
 }
 
-// first sync_short trigger of a slot.  Returns the trigger index or -1; A_t = A[trigger].
-// The tiles are walked in order (each needs the block sums of the one before), but the samples of the first
-// WR_DETECT_AHEAD of them are requested up front by detect_load() -- for all four slots of a wave before the first
-// scan starts -- so that a frame within the usual lead-in is found without a further memory round trip.
-struct DetectAhead { c32 xn[WR_DETECT_AHEAD], xd[WR_DETECT_AHEAD]; };
+// first sync_short trigger of each of the FOUR slots of a wave, in lock step (batch mode): row f = lanes 16f..16f+15 walks
+// slot f in blocks of 16 samples, lane r of the row <-> sample 16m + r of block m.  The spec's 16-sample blocks (rule 3) are
+// then exactly a DPP row: prefix H and suffix T are row scans, the block total B = H[15] is a row broadcast, and what a
+// window needs of the three or four blocks before -- T of block m-3 (m-4 for the power window), B of blocks m-1 .. m-3 --
+// are this lane's own values of earlier steps, carried in registers.  x[n-16] is the lane's sample of the step before.
+// No cross-row traffic at all (the lane <-> sample form above fetched 18 values per 64-sample tile through ds_bpermute and
+// walked the four slots one after the other).  Same sums in the same order: bit-identical A, P and triggers.
+// The samples are requested four blocks (64 samples per slot) ahead.
+struct DetectQuadState {
+    c32   xd;                     // x[n - 16]
+    float Tr[3], Ti[3], Tp[4];    // tails of blocks m-1, m-2, m-3 (, m-4) at this lane's r
+    float Br[2], Bi[2], Bp[3];    // totals of blocks m-1, m-2 (, m-3)
+};
 
-__device__ __forceinline__ void detect_load(const float2* __restrict__ x, long n_samp, int lane, DetectAhead& d)
+#define WR_DQ_GROUP 4             // blocks per request group
+
+__device__ __forceinline__ void detect_quad_load(const float2* __restrict__ x, int n_samp, int m0, int r, c32 (&v)[WR_DQ_GROUP])
 {
 #pragma unroll
-    for (int k = 0; k < WR_DETECT_AHEAD; k++) {
-        d.xn[k] = load_sample(x, 64 * k + lane, n_samp);
-        d.xd[k] = load_sample(x, 64 * k + lane - 16, n_samp);
+    for (int k = 0; k < WR_DQ_GROUP; k++) {
+        const int n = 16 * (m0 + k) + r;
+        float2 t = make_float2(0.0f, 0.0f);
+        if (n < n_samp) t = x[n];
+        v[k] = { t.x, t.y };
     }
 }
 
-__device__ __forceinline__ int detect_first(const float2* __restrict__ x, long n_samp, float thr,
-                                            int min_plateau, int lane, const DetectAhead& d, c32& A_t)
+// One block of all four slots.  Returns the ballot of c[n] > thr (bits 16f .. 16f+15: slot f's block); Ar/Ai = A[n] of this
+// lane's sample.
+__device__ __forceinline__ uint64_t detect_quad_step(c32 xn, int n, int n_samp, float thr, DetectQuadState& st, float& Ar, float& Ai)
 {
-    DetectState ps = detect_state_zero();
-    uint64_t prev_mask = 0;
+    const c32 xd = st.xd;
+    const float ar = fma_(xn.im, xd.im, xn.re * xd.re);
+    const float ai = fma_(xn.im, xd.re, -(xn.re * xd.im));
+    const float pw = fma_(xn.im, xn.im, xn.re * xn.re);
+    const float Hr = row_prefix16(ar), Hi = row_prefix16(ai), Hp = row_prefix16(pw);
+    const float Tr = dpp_zero<0x101>(row_suffix16(ar));
+    const float Ti = dpp_zero<0x101>(row_suffix16(ai));
+    const float Tp = dpp_zero<0x101>(row_suffix16(pw));
+    Ar = ((st.Tr[2] + st.Br[1]) + st.Br[0]) + Hr;
+    Ai = ((st.Ti[2] + st.Bi[1]) + st.Bi[0]) + Hi;
+    const float P = (((st.Tp[3] + st.Bp[2]) + st.Bp[1]) + st.Bp[0]) + Hp;
+    const float m2 = fma_(Ai, Ai, Ar * Ar);
+    const float tp = thr * P;
+    const bool above = (m2 > tp * tp) && (n < n_samp);
+    st.xd = xn;
+    st.Tr[2] = st.Tr[1]; st.Tr[1] = st.Tr[0]; st.Tr[0] = Tr;
+    st.Ti[2] = st.Ti[1]; st.Ti[1] = st.Ti[0]; st.Ti[0] = Ti;
+    st.Tp[3] = st.Tp[2]; st.Tp[2] = st.Tp[1]; st.Tp[1] = st.Tp[0]; st.Tp[0] = Tp;
+    st.Br[1] = st.Br[0]; st.Br[0] = row_bcast<15>(Hr);
+    st.Bi[1] = st.Bi[0]; st.Bi[0] = row_bcast<15>(Hi);
+    st.Bp[2] = st.Bp[1]; st.Bp[1] = st.Bp[0]; st.Bp[0] = row_bcast<15>(Hp);
+    return __ballot(above);
+}
+
+// x / n_samp: this lane's slot (uniform inside a row; n_samp = 0: no such slot).  t[f] = trigger of slot f or -1, A[f] = A[t[f]].
+__device__ __forceinline__ void detect_quad(const float2* __restrict__ x, int n_samp, float thr, int min_plateau, int lane,
+                                            int (&t)[4], c32 (&A)[4])
+{
+    const int r = lane & 15;
+    DetectQuadState st = {};
+    // per slot: the c > thr bits of the last four blocks, newest block in bits 48..63 (bit 48 + k = sample 16 m + k)
+    uint64_t hist[4] = { 0, 0, 0, 0 };
+    int ns[4];
 #pragma unroll
-    for (int k = 0; k < WR_DETECT_AHEAD; k++) {
-        if (64 * k >= n_samp) return -1;
-        float Ar, Ai;
-        uint64_t mask = detect_tile_core(d.xn[k], d.xd[k], n_samp, 64 * k, thr, lane, ps, Ar, Ai);
-        uint64_t hit = plateau_hits(mask, prev_mask, min_plateau);
-        if (hit) {
-            int l = __builtin_ctzll(hit);
-            A_t = { bcast(Ar, l), bcast(Ai, l) };
-            return 64 * k + l;
+    for (int f = 0; f < 4; f++) { t[f] = -1; A[f] = { 0.0f, 0.0f }; ns[f] = __builtin_amdgcn_readlane(n_samp, 16 * f); }
+    const int n_max = max(max(ns[0], ns[1]), max(ns[2], ns[3]));
+    c32 nx[WR_DQ_GROUP];
+    detect_quad_load(x, n_samp, 0, r, nx);
+    for (int m0 = 0; 16 * m0 < n_max; m0 += WR_DQ_GROUP) {
+        c32 cx[WR_DQ_GROUP];
+#pragma unroll
+        for (int k = 0; k < WR_DQ_GROUP; k++) cx[k] = nx[k];
+        detect_quad_load(x, n_samp, m0 + WR_DQ_GROUP, r, nx);
+#pragma unroll
+        for (int k = 0; k < WR_DQ_GROUP; k++) {
+            const int m = m0 + k;
+            float Ar, Ai;
+            const uint64_t bal = detect_quad_step(cx[k], 16 * m + r, n_samp, thr, st, Ar, Ai);
+            bool open = false;                     // a slot still searching with samples left
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                hist[f] = (hist[f] >> 16) | (((bal >> (16 * f)) & 0xffffull) << 48);
+                if (t[f] < 0 && (hist[f] >> 48)) {                        // wave-uniform
+                    uint64_t hit = hist[f];
+                    for (int j = 1; j <= min_plateau; j++) hit &= hist[f] << j;       // min_plateau <= 32: three blocks of history suffice
+                    hit >>= 48;
+                    if (hit) {
+                        const int l = __builtin_ctzll(hit);
+                        t[f] = 16 * m + l;
+                        A[f] = { bcast(Ar, 16 * f + l), bcast(Ai, 16 * f + l) };
+                    }
+                }
+                open |= t[f] < 0 && 16 * (m + 1) < ns[f];
+            }
+            if (!open) return;
         }
-        prev_mask = mask;
     }
-    for (long n0 = 64 * WR_DETECT_AHEAD; n0 < n_samp; n0 += 64) {
-        float Ar, Ai;
-        uint64_t mask = detect_tile(x, n_samp, n0, thr, lane, ps, Ar, Ai);
-        uint64_t hit = plateau_hits(mask, prev_mask, min_plateau);
-        if (hit) {
-            int l = __builtin_ctzll(hit);
-            A_t = { bcast(Ar, l), bcast(Ai, l) };
-            return (int)(n0 + l);
-        }
-        prev_mask = mask;
-    }
-    return -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,7 +223,9 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
     // correlation of both on the matrix cores, the peak search per slot.
     PreFrame pf[4];
     {
-        DetectAhead da[4];
+        const int row_ = lane >> 4;
+        const float2* xrow = iq;                    // this lane's slot (row f = slot f)
+        int nrow = 0;
 #pragma unroll
         for (int f = 0; f < 4; f++) {
             const uint32_t slot = slot0 + f;
@@ -180,14 +235,13 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
             const size_t off = slot_off ? (size_t)slot_off[sk] : (size_t)sk * slot_len;
             const long len = slot_off ? (long)(slot_off[sk + 1] - slot_off[sk]) : (long)slot_len;
             pf[f] = { iq + off, has ? len : 0l, -1, 0, 0.0f, false, has ? (long)slot : -1l };
-            detect_load(pf[f].x, pf[f].n_samp, lane, da[f]);
+            if (row_ == f) { xrow = pf[f].x; nrow = (int)pf[f].n_samp; }
         }
         c32 A4[4];
+        int t4[4];
+        detect_quad(xrow, nrow, prm.threshold, prm.min_plateau, lane, t4, A4);
 #pragma unroll
-        for (int f = 0; f < 4; f++) {
-            A4[f] = { 0, 0 };
-            pf[f].t = detect_first(pf[f].x, pf[f].n_samp, prm.threshold, prm.min_plateau, lane, da[f], A4[f]);
-        }
+        for (int f = 0; f < 4; f++) pf[f].t = t4[f];
         // coarse CFO of the four slots in ONE pass of the arctangent: row f of the wave works on slot f
         float cfo4;
         {
