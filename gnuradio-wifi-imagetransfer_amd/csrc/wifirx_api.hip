@@ -59,6 +59,7 @@ struct wifirx_handle {
     // decode workspace
     void*  dec_scratch = nullptr;   size_t dec_scratch_bytes = 0;
     void*  dec_max = nullptr;       size_t dec_max_bytes = 0;
+    void*  dec_perm = nullptr;      size_t dec_perm_bytes = 0;    // decode_mac over several rates: frames grouped by rate
     void*  dec_hbits = nullptr;     size_t dec_hbits_bytes = 0;   // decode_mac over `idx` alone: its bit planes (wifirx_out.hbits form)
     void*  s_pack = nullptr;        size_t s_pack_bytes = 0;      // stream outputs, rows cut to their filled width
     void*  s_host = nullptr;        size_t s_host_bytes = 0;      // pinned landing zone of the packed outputs
@@ -217,6 +218,7 @@ int wifirx_destroy(wifirx_handle* h)
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (h->s_pack) (void)hipFree(h->s_pack);
     if (h->dec_hbits) (void)hipFree(h->dec_hbits);
+    if (h->dec_perm) (void)hipFree(h->dec_perm);
     if (h->s_host) (void)hipHostFree(h->s_host);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

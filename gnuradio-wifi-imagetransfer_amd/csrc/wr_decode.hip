@@ -353,8 +353,11 @@ __global__ __launch_bounds__(256, WR_DEC_WAVES_PER_SIMD)
 void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
                    const uint32_t* __restrict__ hbits_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
                    uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total,
-                   uint32_t frames_per_wave)
+                   uint32_t frames_per_wave, const uint32_t* __restrict__ perm, uint32_t n_virtual)
 {
+    // perm != nullptr: the wave's frames are perm[base + ...] (0xffffffff: no frame) -- the decodable frames of a batch
+    // with several rates, grouped by rate into runs that start on task boundaries (decode_perm_kernel), so that every
+    // task is of one rate; perm == nullptr: frame k is slot k, n_virtual = n_slots.
     // the current OFDM symbols of the wave's frames, lane-private columns.  One rate: row 2 w + g (w = word of the staged
     // block, g = 0, 1) = 16-bit plane g of the word of frame A | that of frame B << 16 (plane p of a symbol = row 2 n_w s + p
     // for the s-th symbol of the block); mixed rates: row 12 h + k = word k of the current symbol of the frame of half h.
@@ -379,24 +382,29 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
     // A wave's tasks (frames_per_wave <= 128 frames each, grid-stride); lane l owns frames base + l (l < fA) and
     // base + fA + l (l < fB).
     const uint32_t fA = frames_per_wave < 64 ? frames_per_wave : 64, fB = frames_per_wave - fA;
-    const uint32_t n_tasks = (n_slots + frames_per_wave - 1) / frames_per_wave;
+    const uint32_t n_tasks = (n_virtual + frames_per_wave - 1) / frames_per_wave;
     for (uint32_t task = wave; task < n_tasks; task += n_waves_total) {
         const uint32_t base = task * frames_per_wave;
-        const uint32_t* hb_task = hbits_all + (size_t)base * hb_stride;
         // ---- my two frames ----
         int n_data[2], enc[2];
+        uint32_t slot_of[2];
         int n_max = 0;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const uint32_t slot = base + (h ? fA : 0u) + lane;
+            const uint32_t v = base + (h ? fA : 0u) + lane;
+            uint32_t slot = 0xffffffffu;
+            if ((uint32_t)lane < (h ? fB : fA) && v < n_virtual) slot = perm ? perm[v] : v;
             n_data[h] = 0;
             enc[h] = 0;
-            if ((uint32_t)lane < (h ? fB : fA) && slot < n_slots) {
+            if (slot < n_slots) {
                 enc[h] = frames[slot].encoding & 7;
                 n_data[h] = frame_steps(frames[slot].flags, enc[h], frames[slot].psdu_len, psdu_stride, max_sym, n_steps_cap);
             }
+            slot_of[h] = slot < n_slots ? slot : 0u;
             n_max = n_data[h] > n_max ? n_data[h] : n_max;
         }
+        const uint32_t* rowA = hbits_all + (size_t)slot_of[0] * hb_stride;      // my frames' plane rows
+        const uint32_t* rowB = hbits_all + (size_t)slot_of[1] * hb_stride;
 #pragma unroll
         for (int k = 1; k < 64; k <<= 1) {
             int o = __shfl_xor(n_max, k, 64);
@@ -414,7 +422,6 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
         const int nw_u = enc_u < 2 ? 2 : enc_u < 4 ? 4 : enc_u < 6 ? 8 : 12;        // words per symbol
         const int sym_blk = enc_u < 2 ? 8 : enc_u < 4 ? 4 : enc_u < 6 ? 2 : 1;      // symbols staged together (one rate)
         const int n_ld = enc_u < 6 ? 16 : 12;                                       // = sym_blk * nw_u words
-        const uint32_t offA = (uint32_t)lane * hb_stride, offB = (fA + (uint32_t)lane) * hb_stride;
 
         // ---- phase 2: add-compare-select ----
         uint32_t pm[64];
@@ -441,8 +448,8 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                 if (tt_u == nd_u) { tt_u = 0; sym_u++; }
                 if (tt_u == 0 && (sym_u & (sym_blk - 1)) == 0) {
                     const bool okA = tg < n_data[0], okB = tg < n_data[1];
-                    const uint32_t* pa = hb_task + offA + (uint32_t)(sym_u * nw_u);
-                    const uint32_t* pb = hb_task + offB + (uint32_t)(sym_u * nw_u);
+                    const uint32_t* pa = rowA + (uint32_t)(sym_u * nw_u);
+                    const uint32_t* pb = rowB + (uint32_t)(sym_u * nw_u);
                     const uint32_t room = hb_stride - (uint32_t)(sym_u * nw_u);      // words left in a frame's row
 #pragma unroll
                     for (int k = 0; k < 16; k += 4) {
@@ -465,7 +472,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
                     if ((int)(pos[h] & 0xffu) == nd) pos[h] = (pos[h] & ~0xffu) + 0x100u;
                     if ((pos[h] & 0xffu) == 0u && tg < n_data[h]) {
                         const int nw = enc[h] < 2 ? 2 : enc[h] < 4 ? 4 : enc[h] < 6 ? 8 : 12;
-                        const uint32_t* ps = hb_task + (h ? offB : offA) + (pos[h] >> 8) * (uint32_t)nw;
+                        const uint32_t* ps = (h ? rowB : rowA) + (pos[h] >> 8) * (uint32_t)nw;
                         for (int k = 0; k < nw; k++) symw[(12 * h + k) * 64] = ps[k];
                     }
                 }
@@ -643,7 +650,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if (n_data[h] > 0) {                               // the record is re-read: nothing of it was kept in registers
-                const uint32_t slot = base + (h ? fA : 0u) + lane;
+                const uint32_t slot = slot_of[h];
                 finish_frame(dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
                              ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags, ft);
             }
@@ -804,29 +811,62 @@ void decode_small_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __res
     }
 }
 
-// longest trellis (in steps) among the frames decode_kernel would accept
+// longest trellis (in steps) among the frames decode_kernel would accept -> out[0]; how many of them there are per
+// rate -> out[1 + enc]
 __global__ __launch_bounds__(256)
 void decode_maxsteps_kernel(uint32_t n_slots, uint32_t max_sym, const wifirx_frame* __restrict__ frames,
                             uint32_t psdu_stride, uint32_t* __restrict__ out)
 {
     const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
     uint32_t best = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x) {
-        const wifirx_frame fr = frames[i];
-        const int nd = ndbps_tab[fr.encoding & 7], len = fr.psdu_len;
-        const int n_sym = (16 + 8 * len + 6 + nd - 1) / nd;
-        if ((fr.flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride && len <= WIFIRX_MAX_PSDU &&
-            n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym) {
-            uint32_t v = (uint32_t)(n_sym * nd);
-            best = v > best ? v : best;
+    uint32_t cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };          // wave-uniform (counted by ballot)
+    const uint32_t n_round = (n_slots + 63u) & ~63u;         // whole waves walk the loop: the ballots need every lane
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        int enc = -1;
+        if (i < n_slots) {
+            const wifirx_frame fr = frames[i];
+            const int nd = ndbps_tab[fr.encoding & 7], len = fr.psdu_len;
+            const int n_sym = (16 + 8 * len + 6 + nd - 1) / nd;
+            if ((fr.flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride && len <= WIFIRX_MAX_PSDU &&
+                n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym) {
+                uint32_t v = (uint32_t)(n_sym * nd);
+                best = v > best ? v : best;
+                enc = fr.encoding & 7;
+            }
         }
+#pragma unroll
+        for (int e = 0; e < 8; e++) cnt[e] += (uint32_t)__builtin_popcountll(__ballot(enc == e));
     }
 #pragma unroll
     for (int k = 1; k < 64; k <<= 1) {
         uint32_t o = __shfl_xor(best, k, 64);
         best = o > best ? o : best;
     }
-    if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+    if ((threadIdx.x & 63) == 0) {
+        if (best) atomicMax(out, best);
+#pragma unroll
+        for (int e = 0; e < 8; e++) if (cnt[e]) atomicAdd(out + 1 + e, cnt[e]);
+    }
+}
+
+// The decodable frames of a batch grouped by rate: perm[start[enc] + k] = slot of the k-th such frame found (the order
+// inside a run is whatever the atomics make it -- which frames share a wave does not change any frame's result).  The
+// runs start on task boundaries (start[] from the host), so every task of decode_kernel is of one rate; entries between
+// the runs stay 0xffffffff (set by the caller).
+struct PermStarts { uint32_t s[8]; };
+__global__ __launch_bounds__(256)
+void decode_perm_kernel(uint32_t n_slots, uint32_t max_sym, const wifirx_frame* __restrict__ frames, uint32_t psdu_stride,
+                        PermStarts start, uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm)
+{
+    const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x) {
+        const wifirx_frame fr = frames[i];
+        const int enc = fr.encoding & 7, nd = ndbps_tab[enc], len = fr.psdu_len;
+        const int n_sym = (16 + 8 * len + 6 + nd - 1) / nd;
+        if ((fr.flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride && len <= WIFIRX_MAX_PSDU &&
+            n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym)
+            perm[start.s[enc] + atomicAdd(cursor + enc, 1u)] = i;
+    }
 }
 
 }  // namespace wr
@@ -854,15 +894,31 @@ extern "C" hipError_t wr_launch_decode_pack(hipStream_t st, uint32_t n_slots, ui
 
 extern "C" hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                                        const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
-                                       size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave)
+                                       size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
+                                       const uint32_t* perm, uint32_t n_virtual)
 {
     if (n_slots == 0 || n_waves == 0) return hipSuccess;
-    // the tasks with one rate, then those with several (each kernel skips the other's; the scratch is shared)
+    if (!perm) n_virtual = n_slots;
+    // the tasks with one rate, then those with several (each kernel skips the other's; the scratch is shared).  With a
+    // permutation every task is of one rate and the second kernel has nothing to do.
     uint32_t blocks = (n_waves + 3) / 4;
     hipLaunchKernelGGL(wr::decode_kernel<false>, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
-                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave);
-    hipLaunchKernelGGL(wr::decode_kernel<true>, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
-                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave);
+                       psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual);
+    if (!perm)
+        hipLaunchKernelGGL(wr::decode_kernel<true>, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
+                           psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t wr_launch_decode_perm(hipStream_t st, uint32_t n_slots, uint32_t max_sym, const wifirx_frame* frames,
+                                            uint32_t psdu_stride, const uint32_t* starts8, uint32_t* cursor8, uint32_t* perm)
+{
+    if (n_slots == 0) return hipSuccess;
+    wr::PermStarts ps;
+    for (int e = 0; e < 8; e++) ps.s[e] = starts8[e];
+    uint32_t blocks = (n_slots + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wr::decode_perm_kernel, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, psdu_stride, ps, cursor8, perm);
     return hipGetLastError();
 }
 
