@@ -859,13 +859,29 @@ void decode_perm_kernel(uint32_t n_slots, uint32_t max_sym, const wifirx_frame* 
                         PermStarts start, uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm)
 {
     const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += gridDim.x * blockDim.x) {
-        const wifirx_frame fr = frames[i];
-        const int enc = fr.encoding & 7, nd = ndbps_tab[enc], len = fr.psdu_len;
-        const int n_sym = (16 + 8 * len + 6 + nd - 1) / nd;
-        if ((fr.flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride && len <= WIFIRX_MAX_PSDU &&
-            n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym)
-            perm[start.s[enc] + atomicAdd(cursor + enc, 1u)] = i;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_round = (n_slots + 63u) & ~63u;         // whole waves walk the loop: the ballots need every lane
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        int enc = -1;
+        if (i < n_slots) {
+            const wifirx_frame fr = frames[i];
+            const int e = fr.encoding & 7, nd = ndbps_tab[e], len = fr.psdu_len;
+            const int n_sym = (16 + 8 * len + 6 + nd - 1) / nd;
+            if ((fr.flags & WIFIRX_F_COMPLETE) && len <= (int)psdu_stride && len <= WIFIRX_MAX_PSDU &&
+                n_sym <= WIFIRX_MAX_SYM && n_sym <= (int)max_sym)
+                enc = e;
+        }
+        // one atomic per wave and rate (a million lanes adding to eight counters would queue up behind each other); the
+        // frames of a wave keep their order inside the run
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint64_t m = __ballot(enc == e);
+            if (m == 0) continue;                                   // wave-uniform
+            uint32_t at = 0;
+            if (lane == (int)__builtin_ctzll(m)) at = atomicAdd(cursor + e, (uint32_t)__builtin_popcountll(m));
+            at = (uint32_t)__builtin_amdgcn_readlane((int)at, (int)__builtin_ctzll(m));
+            if (enc == e) perm[start.s[e] + at + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+        }
     }
 }
 

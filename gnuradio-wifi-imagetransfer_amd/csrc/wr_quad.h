@@ -808,31 +808,6 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     const uint64_t xf = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(xv >> 32), has_l) << 32) |
                         (uint32_t)__builtin_amdgcn_readlane((int)xv, has_l);
     const float2* xb = has ? seed.x + t16 : reinterpret_cast<const float2*>(xf);
-    // The symbol loads of the fast path address the samples as ONE wave-uniform base (scalar registers) + a 32-bit byte
-    // offset per lane: global_load with an SGPR base -- no 64-bit address arithmetic per load, and not the flat path
-    // (which a per-lane 64-bit pointer of unknown address space takes and which ties the loads to the LDS counter).
-    // The four frames of a wave lie within 4 GB of each other unless a caller hands over giant slots of unequal length;
-    // then (`near` false) the per-lane pointer form below is used.
-    typedef __attribute__((address_space(1))) const char* gchar_p;
-    typedef float wr_f2 __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(1))) const wr_f2* gfloat2_p;
-    uint64_t xb_base;
-    bool near;
-    uint32_t xb_off;
-    {
-        const uint64_t xu = reinterpret_cast<uint64_t>(xb);
-        uint64_t lo = ~0ull, hi = 0;
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-            const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(xu >> 32), 16 * f) << 32) |
-                               (uint32_t)__builtin_amdgcn_readlane((int)xu, 16 * f);
-            lo = v < lo ? v : lo;
-            hi = v > hi ? v : hi;
-        }
-        xb_base = lo;
-        near = (hi - lo) < 0xf0000000ull;                      // + at most 43 520 samples of 8 bytes per frame
-        xb_off = (uint32_t)(xu - lo);
-    }
     const int   m_lo = has ? (int)(t16 < 0 ? -t16 : 0) : 0;
     const long  m_hi_l = seed.n_samp - t16;
     const int   m_hi = has ? (int)(m_hi_l > 0x7fffff00l ? 0x7fffff00l : m_hi_l) : 0;
@@ -951,16 +926,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             if (lo_zero) {              // act => off0 + 63 < L <= m_hi: every sample of the symbol is in range
                 // rows without a symbol read the first 64 samples of their (or the wave's first) frame instead: finite
                 // numbers that no output sees -- cheaper than zeroing eight registers per symbol for them
-                if (near) {
-                    const uint32_t vo = xb_off + (uint32_t)((act ? off0 : 0) + r) * 8u;
-                    const gchar_p gl = (gchar_p)xb_base + vo;           // scalar base + zero-extended lane offset; 128 j = immediate
+                const float2* p = xb + ((act ? off0 : 0) + r);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { const wr_f2 t = *(gfloat2_p)(gl + 128 * j); cur[j] = { t.x, t.y }; }
-                } else {
-                    const float2* p = xb + ((act ? off0 : 0) + r);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { const float2 t = p[16 * j]; cur[j] = { t.x, t.y }; }
-                }
+                for (int j = 0; j < 4; j++) { const float2 t = p[16 * j]; cur[j] = { t.x, t.y }; }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
