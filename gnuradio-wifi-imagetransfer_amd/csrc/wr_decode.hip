@@ -26,6 +26,7 @@
 // state), start state 0.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "wifirx.h"
 #include "wr_kernels.h"
@@ -278,10 +279,11 @@ __device__ __forceinline__ void build_finish_tables(FinishTables& ft)
 }
 
 // descramble (x^7+x^4+1, state from the first 7 decoded bits), bytes, CRC-32 of one frame; db = its decoded words
-// (stride 128 dwords, two spare words behind the last one).  Four PSDU bytes per iteration: the 32 decoded bits from
+// (stride DBS dwords, two spare words behind the last one).  Four PSDU bytes per iteration: the 32 decoded bits from
 // position 16 + 32 k on (a funnel shift of two decoded words), the 32 scrambler bits from the table (the state after
 // them is their last seven, reversed), CRC by four table look-ups.  Bytes leave four at a time when the row is
 // dword-aligned (wave-uniform `dword_ok`).
+template <int DBS = 128>
 __device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, int psdu_len, uint8_t* __restrict__ psdu,
                                              bool dword_ok, wifirx_frame* __restrict__ rec, uint32_t flags,
                                              const FinishTables& ft)
@@ -297,10 +299,10 @@ __device__ __forceinline__ void finish_frame(const uint32_t* __restrict__ db, in
         state = ((state << 1) & 0x7e) | fb;
     }
     uint32_t crc = 0xffffffffu;
-    uint32_t nxt = db[128];
+    uint32_t nxt = db[DBS];
     const int n_words = psdu_len >> 2;
     for (int k = 0; k < n_words; k++) {
-        const uint32_t nn = db[(size_t)(k + 2) * 128];                     // spare words behind the last one keep this in range
+        const uint32_t nn = db[(size_t)(k + 2) * DBS];                     // spare words behind the last one keep this in range
         const uint32_t sc = ft.scr[state];
         state = (int)(__builtin_bitreverse32(sc) & 0x7fu);
         const uint32_t d = __builtin_amdgcn_alignbit(nxt, cur, 16) ^ sc;    // positions 16 + 32 k .. + 31, descrambled
@@ -659,6 +661,348 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// decode_q_kernel: the throughput decoder with FOUR frames per lane (256 per wave), path metrics a byte each in one
+// register ("SWAR").  For batches that fill the GPU with such waves (about a million frames per call); every task is of
+// one rate (a batch of several rates comes grouped by rate, decode_perm_kernel).
+//
+// What makes bytes enough.  After six steps every state has a survivor that started in state 0, and from then on the
+// 64 path metrics of a frame lie within 12 of each other: any state is reached from the best state of six steps ago in
+// six steps of at most 2 each.  So (i) the first six steps are not compared at all: a state's metric after them is
+// the sum of the six branch metrics along its only genuine path (a tree of 126 additions), and its survivor bits there
+// are 0 (the other candidate comes from a state that cannot have been reached yet) -- exactly what the oracle's
+// "unreachable = 2^28" start yields; (ii) the common minimum leaves the metrics every 48 steps, so a byte stays below
+// 12 + 2 x 48 + 2 < 128; (iii) the two candidates of a state differ by at most 14, so the byte 127 - c1 + c0 (ONE v_xad_u32:
+// (c1 ^ 0x7f7f7f7f) + c0) lies in 113..141: no carry crosses a byte, bit 7 of it says "c1 < c0" (the strict comparison of
+// the oracle's tie rule) and bits 4, 5, 6 all say the opposite.  One v_bfi_b32 therefore drops a decision into bit 7, 6, 5 or
+// 4 of the accumulator's bytes without a shift (the last three inverted), four decisions, then the accumulator moves
+// down by four; the smaller candidate is picked byte-wise by one v_perm_b32 whose selector is (z >> 5) & 0x04040404 |
+// 0x03020100.  A butterfly (two new states of four frames) is 4 + 2 x 5.1 = 14.3 instructions: 3.6 per frame against 5.25 of
+// the packed-16-bit form of decode_kernel.
+//
+// Bytes of a register: byte 0 = frame l (h = 0), byte 1 = frame 128 + l (h = 2), byte 2 = frame 64 + l (h = 1), byte 3 =
+// frame 192 + l (h = 3) -- the order in which the 16-bit plane halves of two staged words fall into bytes.
+// Survivor words: acc[g] (g = 0..7) holds the decisions of the states 8g .. 8g+7, state 8g + i in bit i ^ 3 of every byte
+// ({3,2,1,0,7,6,5,4}[i]), stored inverted except for i = 0 and i = 4.
+#define WR_DQ_FRAMES    256
+#define WR_DQ_NORM      48
+#define WR_DQ_BYTE(h)   ((h) == 0 ? 0 : (h) == 1 ? 2 : (h) == 2 ? 1 : 3)
+
+__device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    uint32_t r;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "v"(sel));
+    return r;
+}
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o)      // (a & m) | o; m through the scalar unit, o in a register
+{
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(o));
+    return r;
+}
+// byte-wise min(a, b) for bytes below 128 that differ by less than 16
+__device__ __forceinline__ uint32_t min_u8x4(uint32_t a, uint32_t b, uint32_t sel0)
+{
+    const uint32_t y = (b | 0x80808080u) - a;                  // byte: 128 + b - a; bits 4..6 set iff b < a
+    return perm_b32(b, a, and_or(y >> 2, 0x04040404u, sel0));
+}
+
+// (a ^ m) + b: with m = 0x7f7f7f7f and bytes below 128, byte-wise 127 - a + b
+__device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t m, uint32_t b)
+{
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(b));
+    return r;
+}
+
+template <int P>
+__device__ __forceinline__ void acs_step_q(uint32_t (&pm)[64], const uint32_t (&M)[2][2], uint32_t (&acc)[8], uint32_t sel0)
+{
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int a = parity_of((j << 1) & 0155), b = parity_of((j << 1) & 0117);
+        const uint32_t m = M[a][b], mb = M[a ^ 1][b ^ 1];
+        const int r0 = rotr6(j, P), r1 = rotr6(j + 32, P);
+        const uint32_t p0 = pm[r0], p1 = pm[r1];
+        const uint32_t c00 = p0 + m, c01 = p1 + mb, c10 = p0 + mb, c11 = p1 + m;
+        // z = 127 + c0 - c1 per byte (113 .. 141: no carry crosses a byte): bit 7 says "candidate 1 is smaller" (strictly: a tie
+        // keeps candidate 0), bits 4, 5, 6 say the opposite
+        const uint32_t z0 = xad(c01, 0x7f7f7f7fu, c00), z1 = xad(c11, 0x7f7f7f7fu, c10);
+        uint32_t& w = acc[j >> 2];
+        const int i = 2 * (j & 3);                                  // decisions i, i + 1 of this word (states 2j, 2j + 1)
+        if (i == 4) w >>= 4;                                        // the high nibbles are full: make room
+        // i = 0, 4 -> bit 7 and bit 6 (inverted);  i = 2, 6 -> bits 5 and 4 (both inverted)
+        if (i == 0)           w = z0 & 0x80808080u;
+        else if ((i & 3) == 0) w = bfi(0x80808080u, z0, w);
+        else                   w = bfi(0x20202020u, z0, w);
+        w = bfi((i & 3) == 0 ? 0x40404040u : 0x10101010u, z1, w);
+        pm[r0] = perm_b32(c01, c00, and_or(z0 >> 5, 0x04040404u, sel0));
+        pm[r1] = perm_b32(c11, c10, and_or(z1 >> 5, 0x04040404u, sel0));
+    }
+}
+
+template <int ROWS>        // LDS rows per wave: 32 (rates up to 16-QAM: 8 staged words x 4), 48 (64-QAM: one symbol of 12 words)
+__global__ __launch_bounds__(256, ROWS == 32 ? 4 : 3)
+void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
+                     const uint32_t* __restrict__ hbits_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
+                     uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total,
+                     uint32_t frames_per_wave, const uint32_t* __restrict__ perm, uint32_t n_virtual)
+{
+    // the current OFDM symbols of the wave's frames: row 4 w + 2 c + g (w = word of the staged 8-word block, c = 0: frames
+    // h = 0, 1; c = 1: frames h = 2, 3; g = 16-bit plane of the word) = plane of the first frame | that of the second << 16
+    __shared__ uint32_t sym_all[4][ROWS * 64];
+    __shared__ FinishTables ft;
+    build_finish_tables(ft);
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * 4 + wv;
+    if (wave >= n_waves_total) return;
+    uint32_t* symw = sym_all[wv] + lane;
+    const uint32_t sym_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)sym_all[wv]);
+    const size_t n_data_cap = n_steps_cap;
+    uint32_t* surv = reinterpret_cast<uint32_t*>(scratch + (size_t)wave * scratch_stride);   // [step][lane][8 words]
+    uint32_t* dbits = surv + n_data_cap * 512;                                               // [word][h][lane]
+    const uint32_t k1 = 0x01010101u;
+    uint32_t sel0 = 0x03020100u;                      // v_perm_b32 selector "every byte from the second source", kept in a register
+    asm volatile("" : "+v"(sel0));
+    const int ndbps_tab[8] = { 24, 36, 48, 72, 96, 144, 192, 216 };
+    const uint32_t hb_stride = max_sym * 12;
+
+    const uint32_t n_tasks = (n_virtual + frames_per_wave - 1) / frames_per_wave;
+    for (uint32_t task = wave; task < n_tasks; task += n_waves_total) {
+        const uint32_t base = task * frames_per_wave;
+        int n_data[4], enc_any = 0;
+        uint32_t slot_of[4];
+        const uint32_t* row[4];
+        int n_max = 0;
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const uint32_t fi = 64u * h + (uint32_t)lane;          // frame of the task
+            uint32_t slot = 0xffffffffu;
+            if (fi < frames_per_wave && base + fi < n_virtual) slot = perm ? perm[base + fi] : base + fi;
+            n_data[h] = 0;
+            if (slot < n_slots) {
+                const int e = frames[slot].encoding & 7;
+                n_data[h] = frame_steps(frames[slot].flags, e, frames[slot].psdu_len, psdu_stride, max_sym, n_steps_cap);
+                if (n_data[h]) enc_any = e;
+            }
+            slot_of[h] = slot < n_slots ? slot : 0u;
+            row[h] = hbits_all + (size_t)slot_of[h] * hb_stride;
+            n_max = n_data[h] > n_max ? n_data[h] : n_max;
+        }
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) {
+            int o = __shfl_xor(n_max, k, 64);
+            n_max = o > n_max ? o : n_max;
+        }
+        n_max = __builtin_amdgcn_readfirstlane(n_max);
+        if (n_max == 0) continue;
+        // the task's rate (every frame of a task shares it: the caller groups by rate)
+        const uint64_t any = __ballot(n_data[0] > 0 || n_data[1] > 0 || n_data[2] > 0 || n_data[3] > 0);
+        const int enc_u = __builtin_amdgcn_readlane(enc_any, (int)__builtin_ctzll(any));
+        const int nd_u = ndbps_tab[enc_u];
+        const int nw_u = enc_u < 2 ? 2 : enc_u < 4 ? 4 : enc_u < 6 ? 8 : 12;        // words per symbol
+        const int blk_w = enc_u < 6 ? 8 : 12;                                       // words staged together: 4 / 2 / 1 / 1 symbols
+        if (ROWS < 48 && enc_u >= 6) continue;                                      // (the host launches the 48-row instance when 64-QAM frames exist)
+        const int sym_blk = blk_w / nw_u;
+
+        uint32_t pm[64];
+        int best[4] = { 0, 0, 0, 0 };
+        int tt_u = 0, sym_u = 0, since_norm = 0;
+        // one group of six trellis steps; `first`: the group without comparisons (steps 0..5)
+        auto group = [&](auto first_tag, const int tg) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            if (!FIRST && since_norm == WR_DQ_NORM) {
+                since_norm = 0;
+                uint32_t mn = pm[0];
+#pragma unroll
+                for (int s = 1; s < 64; s++) mn = min_u8x4(mn, pm[s], sel0);
+#pragma unroll
+                for (int s = 0; s < 64; s++) pm[s] -= mn;
+            }
+            since_norm += 6;
+            // ---- the next block of bit-plane words, global -> lane-private LDS ----
+            if (tt_u == nd_u) { tt_u = 0; sym_u++; }
+            if (tt_u == 0 && (sym_u % sym_blk) == 0) {
+                const uint32_t w0 = (uint32_t)(sym_u * nw_u);
+                const uint32_t room = hb_stride - w0;
+#pragma unroll
+                for (int k = 0; k < 12; k += 4) {
+                    if (k < blk_w) {
+                        uint4 v[4];
+#pragma unroll
+                        for (int h = 0; h < 4; h++) {
+                            v[h] = make_uint4(0u, 0u, 0u, 0u);
+                            if (tg < n_data[h] && (uint32_t)k + 4 <= room) v[h] = *reinterpret_cast<const uint4*>(row[h] + w0 + k);
+                        }
+                        uint32_t* d = symw + 4 * k * 64;
+#define WR_DQ_ST(W, X) \
+                        d[(4 * W + 0) * 64] = (v[0].X & 0xffffu) | (v[1].X << 16);  d[(4 * W + 1) * 64] = (v[0].X >> 16) | (v[1].X & 0xffff0000u); \
+                        d[(4 * W + 2) * 64] = (v[2].X & 0xffffu) | (v[3].X << 16);  d[(4 * W + 3) * 64] = (v[2].X >> 16) | (v[3].X & 0xffff0000u);
+                        WR_DQ_ST(0, x) WR_DQ_ST(1, y) WR_DQ_ST(2, z) WR_DQ_ST(3, w)
+#undef WR_DQ_ST
+                    }
+                }
+            }
+            const bool mine = tg < n_data[0] || tg < n_data[1] || tg < n_data[2] || tg < n_data[3];
+            // six steps: their coded bits A, B of the four frames as bytes (1 = a one was received), and whether the
+            // position was transmitted at all (wave-uniform: one rate)
+            const uint32_t* te = WR_SRC_TABLE.e + (enc_u * WR_DEC_TAB_STRIDE + tt_u);
+            const uint32_t blk_lds = sym_lds + (uint32_t)((sym_u % sym_blk) * nw_u) * 1024u;      // this symbol's rows (4 rows of 256 B per word)
+            uint32_t e[6];
+#pragma unroll
+            for (int P = 0; P < 6; P++) e[P] = te[P];
+            if (__any(mine)) {
+#pragma unroll
+                for (int Q = 0; Q < 6; Q += 3) {
+                    uint32_t Ms[3][2][2];
+                    {
+                        uint32_t ra[6], wa[6], rc[6], wc[6];
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            // 16-bit plane p = bits 4..8 of the entry: word p >> 1, half p & 1 -> row 4 (p >> 1) + (p & 1) (+ 2: frames 2, 3)
+                            const uint32_t pa = (e[Q + k] >> 4) & 0x1fu, pb = (e[Q + k] >> 20) & 0x1fu;
+                            ra[k] = blk_lds + (4u * (pa >> 1) + (pa & 1u)) * 256u;
+                            ra[3 + k] = blk_lds + (4u * (pb >> 1) + (pb & 1u)) * 256u;
+                            rc[k] = ra[k] + 512u;
+                            rc[3 + k] = ra[3 + k] + 512u;
+                        }
+                        lds_rows6(ra, wa);
+                        lds_rows6(rc, wc);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            const uint32_t ea = e[Q + k] & 0xffffu, eb = e[Q + k] >> 16;
+                            const uint32_t va = k1 & (((ea >> 9) & 1u) - 1u), vb = k1 & (((eb >> 9) & 1u) - 1u);
+                            const uint32_t ta = (((wa[k] >> (ea & 15u)) & 0x00010001u) | (((wc[k] >> (ea & 15u)) & 0x00010001u) << 8)) & va;
+                            const uint32_t tb = (((wa[3 + k] >> (eb & 15u)) & 0x00010001u) | (((wc[3 + k] >> (eb & 15u)) & 0x00010001u) << 8)) & vb;
+                            const uint32_t nv = va + vb;
+                            Ms[k][0][0] = ta + tb;
+                            Ms[k][0][1] = ta + vb - tb;
+                            Ms[k][1][1] = nv - Ms[k][0][0];
+                            Ms[k][1][0] = nv - Ms[k][0][1];
+                        }
+                    }
+                    if constexpr (FIRST) {
+                        // the first six steps without comparisons: the metric of state s = the branch metrics along its one
+                        // path from state 0 (input bits = the bits of s, oldest first); survivor bits 0 (0x77 per byte: the six
+                        // inverted positions)
+                        // (in place in pm: level t reads entries below 2^t and writes entries 2 pp, 2 pp + 1, pp descending)
+                        if (Q == 0) pm[0] = 0u;
+#pragma unroll
+                        for (int t = Q; t < Q + 3; t++) {
+#pragma unroll
+                            for (int pp = (1 << t) - 1; pp >= 0; pp--) {
+                                const int c0 = pp << 1, c1 = (pp << 1) | 1;      // register contents: previous state, input bit
+                                const uint32_t base_m = pm[pp];
+                                pm[c1] = base_m + Ms[t - Q][parity_of(c1 & 0155)][parity_of(c1 & 0117)];
+                                pm[c0] = base_m + Ms[t - Q][parity_of(c0 & 0155)][parity_of(c0 & 0117)];
+                            }
+                        }
+                        if (Q == 3) {
+#pragma unroll
+                            for (int P = 0; P < 6; P++) {
+                                uint4* sp = reinterpret_cast<uint4*>(surv + ((size_t)P * 64 + lane) * 8);
+                                sp[0] = make_uint4(0x77777777u, 0x77777777u, 0x77777777u, 0x77777777u);
+                                sp[1] = make_uint4(0x77777777u, 0x77777777u, 0x77777777u, 0x77777777u);
+                            }
+                        }
+                    } else {
+#define WR_ACS_Q(P, K)                                                                                    \
+                        {                                                                                 \
+                            uint32_t acc[8];                                                              \
+                            acs_step_q<P>(pm, Ms[K], acc, sel0);                                                \
+                            uint4* sp = reinterpret_cast<uint4*>(surv + ((size_t)(tg + P) * 64 + lane) * 8); \
+                            sp[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);                           \
+                            sp[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);                           \
+                        }
+                        if (Q == 0) { WR_ACS_Q(0, 0) WR_ACS_Q(1, 1) WR_ACS_Q(2, 2) }
+                        else        { WR_ACS_Q(3, 0) WR_ACS_Q(4, 1) WR_ACS_Q(5, 2) }
+#undef WR_ACS_Q
+                    }
+                }
+            }
+            {
+                bool endh[4];
+                bool any_end = false;
+#pragma unroll
+                for (int h = 0; h < 4; h++) { endh[h] = tg < n_data[h] && tg + 6 == n_data[h]; any_end |= endh[h]; }
+                if (__any(any_end)) {
+                    // a frame just ended (register phase 0 again): smallest metric, lowest state
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        if (!__any(endh[h])) continue;
+                        const int sh = 8 * WR_DQ_BYTE(h);
+                        uint32_t bm = (pm[0] >> sh) & 0xffu;
+                        int bs = 0;
+#pragma unroll
+                        for (int s2 = 1; s2 < 64; s2++) {
+                            const uint32_t v = (pm[s2] >> sh) & 0xffu;
+                            if (v < bm) { bm = v; bs = s2; }
+                        }
+                        if (endh[h]) best[h] = bs;
+                    }
+                }
+            }
+            tt_u += 6;
+        };
+        group(std::true_type{}, 0);
+        for (int tg = 6; tg < n_max; tg += 6) group(std::false_type{}, tg);
+        __threadfence_block();
+        // ---- traceback of the four frames of a lane: 32 decoded bits per word, words stored [word][h][lane] ----
+        {
+            int st[4] = { best[0], best[1], best[2], best[3] };
+            uint32_t word[4] = { 0u, 0u, 0u, 0u };
+            for (int t1 = n_max - 1; t1 >= 0; t1 -= 4) {
+                // the survivor words of four steps, loaded ahead of the dependent state updates (scalars, selected by
+                // compares: an array indexed by the state would live in scratch memory)
+                uint32_t r0[4], r1[4], r2[4], r3[4], r4[4], r5[4], r6[4], r7[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int t = t1 - k;
+                    uint4 a = make_uint4(0u, 0u, 0u, 0u), b = make_uint4(0u, 0u, 0u, 0u);
+                    if (t >= 0 && (t < n_data[0] || t < n_data[1] || t < n_data[2] || t < n_data[3])) {
+                        const uint4* sp = reinterpret_cast<const uint4*>(surv + ((size_t)t * 64 + lane) * 8);
+                        a = sp[0];
+                        b = sp[1];
+                    }
+                    r0[k] = a.x; r1[k] = a.y; r2[k] = a.z; r3[k] = a.w; r4[k] = b.x; r5[k] = b.y; r6[k] = b.z; r7[k] = b.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int t = t1 - k;
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const bool mine = t >= 0 && t < n_data[h];
+                        const int stv = st[h];
+                        const uint32_t a01 = (stv & 8) ? r1[k] : r0[k], a23 = (stv & 8) ? r3[k] : r2[k];
+                        const uint32_t a45 = (stv & 8) ? r5[k] : r4[k], a67 = (stv & 8) ? r7[k] : r6[k];
+                        const uint32_t a03 = (stv & 16) ? a23 : a01, a47 = (stv & 16) ? a67 : a45;
+                        const uint32_t wsel = (stv & 32) ? a47 : a03;
+                        // bit i ^ 3 of the frame's byte (i = state & 7); stored inverted except at i = 0 and i = 4
+                        const uint32_t bit = (wsel >> (8 * WR_DQ_BYTE(h) + ((stv & 7) ^ 3))) & 1u;
+                        const uint32_t hb = bit ^ (uint32_t)((stv & 3) != 0);
+                        if (mine) {
+                            word[h] |= (uint32_t)(stv & 1) << (t & 31);
+                            st[h] = (stv >> 1) | (int)(hb << 5);
+                            if ((t & 31) == 0) { dbits[(size_t)(t >> 5) * 256 + 64 * h + lane] = word[h]; word[h] = 0; }
+                        }
+                    }
+                }
+            }
+        }
+        __threadfence_block();
+        // ---- descramble, bytes, CRC-32 ----
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            if (n_data[h] > 0) {
+                const uint32_t slot = slot_of[h];
+                finish_frame<256>(dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
+                                  ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags, ft);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The low-latency variant for small batches (stream mode: a few hundred frames per push): one wave per frame,
 // lane <-> trellis state.  An add-compare-select step is two cross-lane reads (ds_bpermute), a handful of vector
 // instructions and one ballot that yields the 64 survivor bits of the step; a frame takes ~0.2 ms instead of the
@@ -922,6 +1266,22 @@ extern "C" hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_
                        psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual);
     if (!perm)
         hipLaunchKernelGGL(wr::decode_kernel<true>, dim3(blocks), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
+                           psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t wr_launch_decode_q(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
+                                         const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
+                                         size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
+                                         const uint32_t* perm, uint32_t n_virtual, int has_64qam)
+{
+    if (n_slots == 0 || n_waves == 0) return hipSuccess;
+    if (!perm) n_virtual = n_slots;
+    if (has_64qam)
+        hipLaunchKernelGGL(wr::decode_q_kernel<48>, dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
+                           psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual);
+    else
+        hipLaunchKernelGGL(wr::decode_q_kernel<32>, dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
                            psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual);
     return hipGetLastError();
 }

@@ -18,7 +18,9 @@
 #define WR_DECODE_MAX_WAVES 4096    // waves of the decode kernel (grid-stride; each owns a scratch slice)
 #define WR_DECODE_SMALL_MAX 16384      // batches up to this many frames take the wave-per-frame decode kernel
 #define WR_DECODE_FRAMES_PER_WAVE 128   // two frames per lane: packed 16-bit path metrics
-#define WR_DECODE_SCRATCH_BUDGET (16ull << 30)   // bytes of survivor scratch a decode call may hold
+#define WR_DECODE_Q_FRAMES_PER_WAVE 256 // four frames per lane: byte path metrics (decode_q_kernel)
+#define WR_DECODE_Q_MIN_FRAMES 600000  // batches from this many decodable frames on fill the GPU with 256-frame waves
+#define WR_DECODE_SCRATCH_BUDGET (24ull << 30)   // bytes of survivor scratch a decode call may hold
 
 namespace wr {
 
@@ -68,6 +70,10 @@ hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, 
                             const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
                             size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
                             const uint32_t* perm, uint32_t n_virtual);
+hipError_t wr_launch_decode_q(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
+                              const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
+                              size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
+                              const uint32_t* perm, uint32_t n_virtual, int has_64qam);
 hipError_t wr_launch_decode_perm(hipStream_t st, uint32_t n_slots, uint32_t max_sym, const wifirx_frame* frames,
                                  uint32_t psdu_stride, const uint32_t* starts8, uint32_t* cursor8, uint32_t* perm);
 hipError_t wr_launch_decode_small(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,

@@ -53,6 +53,22 @@ def test_random_frames_throughput_decoder():
         assert v["total_mismatches"] == 0, (name, v["mismatches"])
 
 
+def test_random_frames_four_frames_per_lane_decoder(monkeypatch):
+    """... and onto decode_q_kernel (four frames per lane), which batches of a million frames take by themselves: random
+    rates (grouped by rate on the device), random lengths inside a wave (frames ending at different steps), bit errors."""
+    import parity_campaign as pc
+    monkeypatch.setenv("WIFIRX_DECODE_Q", "1")
+    monkeypatch.setenv("WIFIRX_DECODE_FPW", "256")
+    res = pc.run(20000, 306, equalisers=(0, 1), decode_small_max=0)
+    _record("frames_seed306_four_frames_per_lane_decoder", res)
+    for name, v in res["equalisers"].items():
+        assert v["total_mismatches"] == 0, (name, v["mismatches"])
+    monkeypatch.setenv("WIFIRX_DECODE_FPW", "0")
+    res = pc.run(1200, 307, long_frames=True, equalisers=(0,), decode_small_max=0)
+    _record("long_frames_seed307_four_frames_per_lane_decoder", res)
+    assert res["equalisers"]["LS"]["total_mismatches"] == 0, res["equalisers"]["LS"]["mismatches"]
+
+
 def test_long_frames_four_equalisers():
     """640 frames of up to 511 OFDM symbols (PSDUs up to 1530 bytes at every rate: the longest decode_mac accepts; the
     renormalisation of its path metrics over 12 000+ trellis steps; the carried derotation phasor over 40 000 samples)."""

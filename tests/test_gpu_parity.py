@@ -87,3 +87,27 @@ def test_decode_mac_full_waves(capi, orc, monkeypatch, encoding, plen, snr):
     assert np.array_equal(r["psdu"][dec][:, :plen], opsdu[dec][:, :plen])
     if snr >= 25:
         assert ((o["frames"]["flags"] & orc.F_CRC_OK) != 0).all() and np.array_equal(r["psdu"][:, :plen], tx.psdu)
+
+
+@pytest.mark.parametrize("encoding,plen,snr", [(2, 294, 25.0), (2, 294, 5.0), (0, 60, 6.0), (7, 294, 19.5), (5, 100, 13.0), (4, 333, 11.0)])
+def test_decode_mac_four_frames_per_lane(capi, orc, monkeypatch, encoding, plen, snr):
+    """decode_q_kernel (four frames per lane, byte path metrics, 256 frames per wave: what batches of a million frames
+    take) forced onto a small batch with every frame position of its waves filled: byte for byte the oracle's PSDUs, at
+    every constellation incl. the 48-row instance for 64-QAM, also where the channel leaves bit errors and ties."""
+    monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "0")
+    monkeypatch.setenv("WIFIRX_DECODE_Q", "1")
+    monkeypatch.setenv("WIFIRX_DECODE_FPW", "256")
+    n = 600                                                   # two full waves + one with 88 frames
+    iq, slot_len, tx = make_slots(n, encoding, psdu_len=plen, snr_db=snr, seed=300 + encoding)
+    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=0)
+    r = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=384)
+    rx.close()
+    prm = orc.make_params(max_sym=tx.n_sym)
+    o = orc.demod_batch(iq, slot_len, prm, n_threads=8)
+    opsdu = orc.decode_batch(o["frames"], o["idx"], prm, psdu_stride=384, n_threads=8)
+    assert np.array_equal(r["frames"], o["frames"])
+    dec = (o["frames"]["flags"] & orc.F_DECODED) != 0
+    assert dec.sum() > 40
+    assert np.array_equal(r["psdu"][dec][:, :plen], opsdu[dec][:, :plen])
+    if snr >= 25:
+        assert ((o["frames"]["flags"] & orc.F_CRC_OK) != 0).all() and np.array_equal(r["psdu"][:, :plen], tx.psdu)
