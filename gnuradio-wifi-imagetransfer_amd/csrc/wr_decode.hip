@@ -706,6 +706,12 @@ __device__ __forceinline__ uint32_t min_u8x4(uint32_t a, uint32_t b, uint32_t se
     return perm_b32(b, a, and_or(y >> 2, 0x04040404u, sel0));
 }
 
+__device__ __forceinline__ uint32_t perm_s(uint32_t hi, uint32_t lo, uint32_t sel)      // selector through the scalar unit
+{
+    uint32_t r;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(sel));
+    return r;
+}
 // (a ^ m) + b: with m = 0x7f7f7f7f and bytes below 128, byte-wise 127 - a + b
 __device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t m, uint32_t b)
 {
@@ -714,29 +720,43 @@ __device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t m, uint32_t b)
     return r;
 }
 
+// One trellis step at register phase P.  The survivor words leave in two halves (states 0..31 after the butterflies
+// 0..15, states 32..63 after 16..31), each transposed to per-frame words right away: four accumulators live at a time.
 template <int P>
-__device__ __forceinline__ void acs_step_q(uint32_t (&pm)[64], const uint32_t (&M)[2][2], uint32_t (&acc)[8], uint32_t sel0)
+__device__ __forceinline__ void acs_step_q(uint32_t (&pm)[64], const uint32_t (&M)[2][2], uint32_t sel0, uint32_t* __restrict__ dst)
 {
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-        const int a = parity_of((j << 1) & 0155), b = parity_of((j << 1) & 0117);
-        const uint32_t m = M[a][b], mb = M[a ^ 1][b ^ 1];
-        const int r0 = rotr6(j, P), r1 = rotr6(j + 32, P);
-        const uint32_t p0 = pm[r0], p1 = pm[r1];
-        const uint32_t c00 = p0 + m, c01 = p1 + mb, c10 = p0 + mb, c11 = p1 + m;
-        // z = 127 + c0 - c1 per byte (113 .. 141: no carry crosses a byte): bit 7 says "candidate 1 is smaller" (strictly: a tie
-        // keeps candidate 0), bits 4, 5, 6 say the opposite
-        const uint32_t z0 = xad(c01, 0x7f7f7f7fu, c00), z1 = xad(c11, 0x7f7f7f7fu, c10);
-        uint32_t& w = acc[j >> 2];
-        const int i = 2 * (j & 3);                                  // decisions i, i + 1 of this word (states 2j, 2j + 1)
-        if (i == 4) w >>= 4;                                        // the high nibbles are full: make room
-        // i = 0, 4 -> bit 7 and bit 6 (inverted);  i = 2, 6 -> bits 5 and 4 (both inverted)
-        if (i == 0)           w = z0 & 0x80808080u;
-        else if ((i & 3) == 0) w = bfi(0x80808080u, z0, w);
-        else                   w = bfi(0x20202020u, z0, w);
-        w = bfi((i & 3) == 0 ? 0x40404040u : 0x10101010u, z1, w);
-        pm[r0] = perm_b32(c01, c00, and_or(z0 >> 5, 0x04040404u, sel0));
-        pm[r1] = perm_b32(c11, c10, and_or(z1 >> 5, 0x04040404u, sel0));
+    for (int half = 0; half < 2; half++) {
+        uint32_t acc[4];
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            const int j = 16 * half + jj;
+            const int a = parity_of((j << 1) & 0155), b = parity_of((j << 1) & 0117);
+            const uint32_t m = M[a][b], mb = M[a ^ 1][b ^ 1];
+            const int r0 = rotr6(j, P), r1 = rotr6(j + 32, P);
+            const uint32_t p0 = pm[r0], p1 = pm[r1];
+            const uint32_t c00 = p0 + m, c01 = p1 + mb, c10 = p0 + mb, c11 = p1 + m;
+            // z = 127 + c0 - c1 per byte (113 .. 141: no carry crosses a byte): bit 7 says "candidate 1 is smaller" (strictly: a
+            // tie keeps candidate 0), bits 4, 5, 6 say the opposite
+            const uint32_t z0 = xad(c01, 0x7f7f7f7fu, c00), z1 = xad(c11, 0x7f7f7f7fu, c10);
+            uint32_t& w = acc[jj >> 2];
+            const int i = 2 * (j & 3);                              // decisions i, i + 1 of this word (states 2j, 2j + 1)
+            if (i == 4) w >>= 4;                                    // the high nibbles are full: make room
+            // i = 0, 4 -> bit 7 and bit 6 (inverted);  i = 2, 6 -> bits 5 and 4 (both inverted)
+            if (i == 0)           w = z0 & 0x80808080u;
+            else if ((i & 3) == 0) w = bfi(0x80808080u, z0, w);
+            else                   w = bfi(0x20202020u, z0, w);
+            w = bfi((i & 3) == 0 ? 0x40404040u : 0x10101010u, z1, w);
+            pm[r0] = perm_b32(c01, c00, and_or(z0 >> 5, 0x04040404u, sel0));
+            pm[r1] = perm_b32(c11, c10, and_or(z1 >> 5, 0x04040404u, sel0));
+        }
+        // 4 x 4 byte transpose: T[k] = byte k of acc[0..3] = the decisions of the frame with byte index k, states 32 half ..
+        // 32 half + 31 (byte g' = states 8g' .. 8g'+7)
+        const uint32_t ta = perm_s(acc[1], acc[0], 0x05010400u), tb = perm_s(acc[1], acc[0], 0x07030602u);
+        const uint32_t tc = perm_s(acc[3], acc[2], 0x05010400u), td = perm_s(acc[3], acc[2], 0x07030602u);
+        // row layout: [half][byte index k] -> one 16-byte store per half
+        reinterpret_cast<uint4*>(dst)[half] = make_uint4(perm_s(tc, ta, 0x05040100u), perm_s(tc, ta, 0x07060302u),
+                                                         perm_s(td, tb, 0x05040100u), perm_s(td, tb, 0x07060302u));
     }
 }
 
@@ -772,7 +792,6 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
         const uint32_t base = task * frames_per_wave;
         int n_data[4], enc_any = 0;
         uint32_t slot_of[4];
-        const uint32_t* row[4];
         int n_max = 0;
 #pragma unroll
         for (int h = 0; h < 4; h++) {
@@ -786,7 +805,6 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
                 if (n_data[h]) enc_any = e;
             }
             slot_of[h] = slot < n_slots ? slot : 0u;
-            row[h] = hbits_all + (size_t)slot_of[h] * hb_stride;
             n_max = n_data[h] > n_max ? n_data[h] : n_max;
         }
 #pragma unroll
@@ -832,7 +850,8 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
 #pragma unroll
                         for (int h = 0; h < 4; h++) {
                             v[h] = make_uint4(0u, 0u, 0u, 0u);
-                            if (tg < n_data[h] && (uint32_t)k + 4 <= room) v[h] = *reinterpret_cast<const uint4*>(row[h] + w0 + k);
+                            if (tg < n_data[h] && (uint32_t)k + 4 <= room)          // (the row pointer is formed here, every few dozen steps: registers)
+                                v[h] = *reinterpret_cast<const uint4*>(hbits_all + (size_t)slot_of[h] * hb_stride + w0 + k);
                         }
                         uint32_t* d = symw + 4 * k * 64;
 #define WR_DQ_ST(W, X) \
@@ -906,14 +925,7 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
                             }
                         }
                     } else {
-#define WR_ACS_Q(P, K)                                                                                    \
-                        {                                                                                 \
-                            uint32_t acc[8];                                                              \
-                            acs_step_q<P>(pm, Ms[K], acc, sel0);                                                \
-                            uint4* sp = reinterpret_cast<uint4*>(surv + ((size_t)(tg + P) * 64 + lane) * 8); \
-                            sp[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);                           \
-                            sp[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);                           \
-                        }
+#define WR_ACS_Q(P, K) acs_step_q<P>(pm, Ms[K], sel0, surv + ((size_t)(tg + P) * 64 + lane) * 8);
                         if (Q == 0) { WR_ACS_Q(0, 0) WR_ACS_Q(1, 1) WR_ACS_Q(2, 2) }
                         else        { WR_ACS_Q(3, 0) WR_ACS_Q(4, 1) WR_ACS_Q(5, 2) }
 #undef WR_ACS_Q
@@ -947,47 +959,86 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
         group(std::true_type{}, 0);
         for (int tg = 6; tg < n_max; tg += 6) group(std::false_type{}, tg);
         __threadfence_block();
-        // ---- traceback of the four frames of a lane: 32 decoded bits per word, words stored [word][h][lane] ----
+        // ---- traceback of the four frames of a lane: 32 decoded bits per word, words stored [word][h][lane].  A step of
+        //      a frame reads ITS two survivor words of the row (compile-time positions), picks the half by bit 5 of the
+        //      state and bit (state & 31) ^ 3 of it.  Fast form when all frames of the wave run the full n_max steps:
+        //      blocks of 96 steps = three whole words; before step t the state holds the decoded bits u_t .. u_(t-5), so
+        //      they leave six at a time.  General form: one bit per step, every access predicated on the frame's length. ----
         {
             int st[4] = { best[0], best[1], best[2], best[3] };
             uint32_t word[4] = { 0u, 0u, 0u, 0u };
-            for (int t1 = n_max - 1; t1 >= 0; t1 -= 4) {
-                // the survivor words of four steps, loaded ahead of the dependent state updates (scalars, selected by
-                // compares: an array indexed by the state would live in scratch memory)
-                uint32_t r0[4], r1[4], r2[4], r3[4], r4[4], r5[4], r6[4], r7[4];
+            const bool uni = __all(n_data[0] == n_max && n_data[1] == n_max && n_data[2] == n_max && n_data[3] == n_max);
+            const int n_fast = uni ? (n_max / 96) * 96 : 0;
+#define WR_DQ_PICK(H, LO, HI)                                                                             \
+            (__builtin_amdgcn_ubfe((((st[H] & 32) ? (HI) : (LO)) ^ 0x77777777u), (uint32_t)((st[H] & 31) ^ 3), 1u))
+            for (int t1 = n_max - 1; t1 >= n_fast; t1 -= 4) {
+                // (one array per word position: a select between two elements of ONE array becomes an indexed access, and the
+                // array then lives in scratch memory)
+                uint32_t l0[4], u0[4], l1[4], u1[4], l2[4], u2[4], l3[4], u3[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int t = t1 - k;
                     uint4 a = make_uint4(0u, 0u, 0u, 0u), b = make_uint4(0u, 0u, 0u, 0u);
-                    if (t >= 0 && (t < n_data[0] || t < n_data[1] || t < n_data[2] || t < n_data[3])) {
+                    if (t >= n_fast && (t < n_data[0] || t < n_data[1] || t < n_data[2] || t < n_data[3])) {
                         const uint4* sp = reinterpret_cast<const uint4*>(surv + ((size_t)t * 64 + lane) * 8);
                         a = sp[0];
                         b = sp[1];
                     }
-                    r0[k] = a.x; r1[k] = a.y; r2[k] = a.z; r3[k] = a.w; r4[k] = b.x; r5[k] = b.y; r6[k] = b.z; r7[k] = b.w;
+                    // a = the low words (states 0..31), b = the high words, by byte index; byte index of frame h: 0, 2, 1, 3
+                    l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int t = t1 - k;
+                    const uint32_t hb4[4] = { WR_DQ_PICK(0, l0[k], u0[k]), WR_DQ_PICK(1, l1[k], u1[k]),
+                                              WR_DQ_PICK(2, l2[k], u2[k]), WR_DQ_PICK(3, l3[k], u3[k]) };
 #pragma unroll
                     for (int h = 0; h < 4; h++) {
-                        const bool mine = t >= 0 && t < n_data[h];
-                        const int stv = st[h];
-                        const uint32_t a01 = (stv & 8) ? r1[k] : r0[k], a23 = (stv & 8) ? r3[k] : r2[k];
-                        const uint32_t a45 = (stv & 8) ? r5[k] : r4[k], a67 = (stv & 8) ? r7[k] : r6[k];
-                        const uint32_t a03 = (stv & 16) ? a23 : a01, a47 = (stv & 16) ? a67 : a45;
-                        const uint32_t wsel = (stv & 32) ? a47 : a03;
-                        // bit i ^ 3 of the frame's byte (i = state & 7); stored inverted except at i = 0 and i = 4
-                        const uint32_t bit = (wsel >> (8 * WR_DQ_BYTE(h) + ((stv & 7) ^ 3))) & 1u;
-                        const uint32_t hb = bit ^ (uint32_t)((stv & 3) != 0);
-                        if (mine) {
-                            word[h] |= (uint32_t)(stv & 1) << (t & 31);
-                            st[h] = (stv >> 1) | (int)(hb << 5);
+                        if (t >= n_fast && t < n_data[h]) {
+                            word[h] |= (uint32_t)(st[h] & 1) << (t & 31);
+                            st[h] = (st[h] >> 1) | (int)(hb4[h] << 5);
                             if ((t & 31) == 0) { dbits[(size_t)(t >> 5) * 256 + 64 * h + lane] = word[h]; word[h] = 0; }
                         }
                     }
                 }
             }
+            for (int blk = n_fast / 96 - 1; blk >= 0; blk--) {
+                // the 96 decoded bits of the block per frame: the groups come from the top step down, so every six steps the
+                // register triple moves up by six and the six bits u_(t-5) .. u_t enter at the bottom (a rolled loop: 16 groups)
+                uint32_t aw[4][3] = { { 0u, 0u, 0u }, { 0u, 0u, 0u }, { 0u, 0u, 0u }, { 0u, 0u, 0u } };
+                const uint32_t* srow = surv + ((size_t)(blk * 96 + 90) * 64 + lane) * 8;       // the rows of the group's six steps
+#pragma unroll 1
+                for (int grp = 15; grp >= 0; grp--, srow -= 6 * 512) {
+                    uint32_t l0[6], u0[6], l1[6], u1[6], l2[6], u2[6], l3[6], u3[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const uint4* sp = reinterpret_cast<const uint4*>(srow + (size_t)k * 512);
+                        const uint4 a = sp[0], b = sp[1];
+                        l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
+                    }
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const uint32_t v = __builtin_bitreverse32((uint32_t)st[h]) >> 26;      // u_(t-5) .. u_t, oldest in bit 0
+                        aw[h][2] = __builtin_amdgcn_alignbit(aw[h][2], aw[h][1], 26);      // the triple moves UP by six ...
+                        aw[h][1] = __builtin_amdgcn_alignbit(aw[h][1], aw[h][0], 26);
+                        aw[h][0] = (aw[h][0] << 6) | v;                                      // ... the older steps' bits enter below
+                    }
+#pragma unroll
+                    for (int q = 5; q >= 0; q--) {
+                        const uint32_t h0 = WR_DQ_PICK(0, l0[q], u0[q]), h1 = WR_DQ_PICK(1, l1[q], u1[q]);
+                        const uint32_t h2 = WR_DQ_PICK(2, l2[q], u2[q]), h3 = WR_DQ_PICK(3, l3[q], u3[q]);
+                        st[0] = (st[0] >> 1) | (int)(h0 << 5);
+                        st[1] = (st[1] >> 1) | (int)(h1 << 5);
+                        st[2] = (st[2] >> 1) | (int)(h2 << 5);
+                        st[3] = (st[3] >> 1) | (int)(h3 << 5);
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < 3; w++)
+#pragma unroll
+                    for (int h = 0; h < 4; h++) dbits[(size_t)(blk * 3 + w) * 256 + 64 * h + lane] = aw[h][w];
+            }
+#undef WR_DQ_PICK
         }
         __threadfence_block();
         // ---- descramble, bytes, CRC-32 ----
