@@ -32,13 +32,14 @@ if [ "$PART" = 2 ]; then
     python3 -c "import json; j=json.load(open('$OUT/preamble_only.json')); print('preamble only ms', j['roofline']['kernel_ms'])"
   fi
   python -m pytest tests -m gpu -q > $OUT/pytest_gpu.txt 2>&1; tail -2 $OUT/pytest_gpu.txt
-  cp gpurun_out/r02_gpu_configs.json $OUT/ 2>/dev/null
+  cp gpurun_out/r02_gpu_configs.json gpurun_out/r03_campaign_*.json $OUT/ 2>/dev/null
 fi
 if [ "$PART" = 3 ]; then
-  python tests/campaigns/parity_campaign.py 20000 1 > $OUT/parity_campaign_seed1.json 2> $OUT/c1.err; tail -c 300 $OUT/parity_campaign_seed1.json; echo
-  python tests/campaigns/parity_campaign.py 60000 31 > $OUT/parity_campaign_seed31.json 2> $OUT/c2.err; tail -c 200 $OUT/parity_campaign_seed31.json; echo
-  WIFIRX_DECODE_SMALL_MAX=0 WIFIRX_DECODE_FPW=128 python tests/campaigns/parity_campaign.py 20000 5 > $OUT/parity_campaign_seed5_throughput_decoder.json 2> $OUT/c3.err; tail -c 200 $OUT/parity_campaign_seed5_throughput_decoder.json; echo
-  python tests/campaigns/parity_campaign.py 3000 3 long > $OUT/parity_campaign_long.json 2> $OUT/c4.err; tail -c 200 $OUT/parity_campaign_long.json; echo
-  python tests/campaigns/stream_campaign.py 200 40 2 > $OUT/stream_campaign.json 2> $OUT/c5.err; tail -c 300 $OUT/stream_campaign.json; echo
+  # the bulk parity evidence is part of the -m gpu suite since round 3 (tests/test_gpu_campaign.py writes gpurun_out/r03_campaign_*.json);
+  # here: the larger runs behind it
+  python tests/campaigns/lts_rule6.py 1400 5 0 0.56 > $OUT/lts_rule6_thr56.json 2> $OUT/c1.err; python3 -c "import json; print(json.load(open('$OUT/lts_rule6_thr56.json'))['totals'])"
+  python tests/campaigns/lts_rule6.py 1400 6 0 0.35 > $OUT/lts_rule6_thr35.json 2> $OUT/c2.err; python3 -c "import json; print(json.load(open('$OUT/lts_rule6_thr35.json'))['totals'])"
+  python tests/campaigns/parity_campaign.py 60000 31 > $OUT/parity_campaign_seed31.json 2> $OUT/c3.err; tail -c 200 $OUT/parity_campaign_seed31.json; echo
+  python tests/campaigns/stream_campaign.py 400 40 2 > $OUT/stream_campaign.json 2> $OUT/c5.err; tail -c 300 $OUT/stream_campaign.json; echo
   python tests/campaigns/ber_sweep.py 100000 0 > $OUT/config3_ber_sweep.json 2> $OUT/c6.err; tail -c 300 $OUT/config3_ber_sweep.json; echo
 fi

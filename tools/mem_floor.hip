@@ -18,15 +18,12 @@ __global__ __launch_bounds__(256, 4) void pattern(const float2* __restrict__ x, 
     const float2* xs = x + (size_t)slot * slot_len;
     float acc = 0.0f;
     if (do_preamble) {
-        // detection: tiles of 64 samples (lane = sample) up to the trigger (~ sample 200), each sample and the one 16 back;
-        // then 383 samples from the trigger - 16 on.  Done per slot by the whole wave, as the kernel does.
+        // detection (round 3): row = slot, blocks of 16 samples (lane r <-> sample 16 m + r) up to the trigger (~ sample 210: 14
+        // blocks), every sample once; then, per slot by the whole wave, 383 samples from the trigger - 16 on, as the kernel does.
+        for (int m = 0; m < 14; m++) { float2 a = xs[16 * m + r]; acc += a.x; }
         for (int f = 0; f < 4; f++) {
             const float2* xf = x + (size_t)(slot - row + f) * slot_len;
             if (slot - row + f >= n_slots) break;
-            for (int n0 = 0; n0 < 256; n0 += 64) {
-                float2 a = xf[n0 + lane], b = xf[n0 + lane >= 16 ? n0 + lane - 16 : 0];
-                acc += a.x + b.y;
-            }
             for (int p = 0; p < 6; p++) { float2 a = xf[176 + 64 * p + lane]; acc += a.x; }
         }
     }
