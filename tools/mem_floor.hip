@@ -71,6 +71,59 @@ __global__ __launch_bounds__(256, 4) void pattern(const float2* __restrict__ x, 
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+// Experiment (round 3): the same loads and stores with the NEXT symbol's samples requested before the current symbol's
+// stores are issued (eight more registers per lane in flight): does the memory system want more bytes in flight per wave?
+template <int depth>
+__global__ __launch_bounds__(256, 4) void pattern_prefetch(const float2* __restrict__ x, uint32_t n_slots, int slot_len, int n_sym,
+                                                           uint8_t* __restrict__ idx, float2* __restrict__ llr, float* sink)
+{
+    const int lane = threadIdx.x & 63, row = lane >> 4, r = lane & 15;
+    const uint32_t slot = ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 4) + row;
+    if (slot >= n_slots) return;
+    const float2* xs = x + (size_t)slot * slot_len;
+    float acc = 0.0f;
+    int carrier[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = r + 16 * j;
+        const bool data = (i >= 6 && i <= 58 && i != 11 && i != 25 && i != 32 && i != 39 && i != 53);
+        carrier[j] = data ? (i - 6 - (i > 11) - (i > 25) - (i > 32) - (i > 39) - (i > 53)) : -1;
+    }
+    uint8_t* ip = idx + (size_t)slot * n_sym * 48;
+    float2* lp = llr + (size_t)slot * n_sym * 48;
+    float2 nx[2][4];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) nx[d][j] = (d < depth) ? xs[352 + 64 * d + r + 16 * j] : make_float2(0.f, 0.f);
+    for (int s = 0; s < n_sym + 3; s++) {
+        float2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = nx[0][j];
+        const int sn = s + depth;
+        const int off = 352 + (sn < 2 ? 64 * sn : 128 + 80 * (sn - 2) + 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (depth == 2) nx[0][j] = nx[1][j];
+            if (sn < n_sym + 3) nx[depth - 1][j] = xs[off + r + 16 * j];
+        }
+        if (s >= 3) {
+            const int q = s - 3;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (carrier[j] < 0) { acc += v[j].x; continue; }
+                const unsigned o = (unsigned)(q * 48 + carrier[j]);
+                ip[o] = (uint8_t)((v[j].x > 0.0f) | ((v[j].y > 0.0f) << 1));
+                lp[o] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc += v[j].x + v[j].y;
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
 // store-pattern variants: mode 0 = the kernel's pattern (per bin: one byte + one float2, rows interleaved),
 // 1 = LLR only in that pattern, 2 = idx only in that pattern, 3 = LLR as full lines (lane l of the wave writes
 // 16 B + 8 B of the 1536 contiguous... per-row 384 B: lanes 0..23 of a row-major order), 4 = idx as dwords (12 lanes per row),
@@ -153,6 +206,19 @@ int main(int argc, char** argv)
            "\"loads_only_ms\": %.3f, \"stores_only_ms\": %.3f, \"what\": \"the global loads and stores of demod_batch_kernel on "
            "config 2 (same addresses, order and wave organisation), no arithmetic\"}\n",
            n_slots, res[0], res[1], res[2], res[3]);
+    for (int depth = 1; depth <= 2; depth++) {
+        float best = 1e9f;
+        for (int it = 0; it < 5; it++) {
+            (void)hipEventRecord(e0, 0);
+            if (depth == 1) hipLaunchKernelGGL(pattern_prefetch<1>, dim3((n_slots + 15) / 16), dim3(256), 0, 0, x, n_slots, slot_len, n_sym, idx, llr, o);
+            else            hipLaunchKernelGGL(pattern_prefetch<2>, dim3((n_slots + 15) / 16), dim3(256), 0, 0, x, n_slots, slot_len, n_sym, idx, llr, o);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            if (it > 0 && ms < best) best = ms;
+        }
+        printf("loads %d symbol(s) ahead + stores (no preamble): %8.3f ms\n", depth, best);
+    }
     for (int mode = 0; mode < 6; mode++) {
         float best = 1e9f;
         for (int it = 0; it < 4; it++) {
