@@ -73,6 +73,7 @@ struct wifirx_handle {
     int64_t  stream_batch = 0;      // WIFIRX_P_STREAM_BATCH
     uint32_t decode_small_max = WR_DECODE_SMALL_MAX;   // WIFIRX_P_DECODE_SMALL_MAX
     uint32_t decode_fpw = 0;        // WIFIRX_DECODE_FPW (environment, tests): frames per wave of the throughput decoder
+    int      decode_ovl = -1;       // WIFIRX_DECODE_OVL: 1 / 0 = always / never overlap trace-back and the next task's add-compare-select
     int      decode_q = -1;         // WIFIRX_DECODE_Q (environment, tests): 1 / 0 = always / never the four-frames-per-lane decoder; -1: by batch size
     int32_t  llr_csi = 0;           // WIFIRX_P_LLR_CSI
     int32_t  stream_want_idx = 1;   // WIFIRX_P_STREAM_IDX
@@ -198,6 +199,7 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
     if (const char* e = std::getenv("WIFIRX_DECODE_SMALL_MAX")) h->decode_small_max = (uint32_t)std::strtoul(e, nullptr, 10);   // tests pick the decode kernel with this
     if (const char* e = std::getenv("WIFIRX_DECODE_FPW")) h->decode_fpw = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("WIFIRX_DECODE_Q")) h->decode_q = std::atoi(e) != 0;
+    if (const char* e = std::getenv("WIFIRX_DECODE_OVL")) h->decode_ovl = std::atoi(e) != 0;
     if (const char* e = std::getenv("WIFIRX_TEST_FAIL_ALLOC")) h->test_fail_alloc = std::atoi(e);
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;

@@ -760,8 +760,26 @@ __device__ __forceinline__ void acs_step_q(uint32_t (&pm)[64], const uint32_t (&
     }
 }
 
-template <int ROWS>        // LDS rows per wave: 32 (rates up to 16-QAM: 8 staged words x 4), 48 (64-QAM: one symbol of 12 words)
-__global__ __launch_bounds__(256, ROWS == 32 ? 4 : 3)
+// The trace-back of a task overlapped with the add-compare-select of the wave's NEXT task (template OVL).  Alone, the two
+// phases of all waves of a round coincide: nine milliseconds of pure survivor writes, then every wave reads its 4.9 MB
+// of survivor bits back at once (19 GB, HBM-bound, ~3.8 ms) with the vector ALUs idle.  Overlapped, a wave keeps the finished
+// task as "pending" (its states, its half of the wave's double scratch buffer) and, after every six add-compare-select
+// steps of the next task, walks the pending one back by six steps -- the survivor reads are spread over the next task's
+// arithmetic; only the last task of a wave is walked back on its own.  Two waves per SIMD then (each wave needs two tasks:
+// half as many waves, twice the scratch per wave, 256 registers).  Only tasks whose frames all run the same number of steps
+// are deferred; others are walked back on the spot as before.
+struct TbPending {
+    bool     active;                  // wave-uniform
+    int      st[4];
+    uint32_t slot[4];                 // 0xffffffff: no frame
+    uint32_t aw[4][3];
+    int      blk, grp;                // wave-uniform: next block of 96 steps, next group of six in it
+    const uint32_t* surv;
+    uint32_t* dbits;
+};
+
+template <int ROWS, bool OVL>        // LDS rows per wave: 32 (rates up to 16-QAM: 8 staged words x 4), 48 (64-QAM: one symbol of 12 words)
+__global__ __launch_bounds__(256, OVL ? 2 : (ROWS == 32 ? 4 : 3))
 void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
                      const uint32_t* __restrict__ hbits_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
                      uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total,
@@ -779,8 +797,12 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
     uint32_t* symw = sym_all[wv] + lane;
     const uint32_t sym_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)sym_all[wv]);
     const size_t n_data_cap = n_steps_cap;
-    uint32_t* surv = reinterpret_cast<uint32_t*>(scratch + (size_t)wave * scratch_stride);   // [step][lane][8 words]
-    uint32_t* dbits = surv + n_data_cap * 512;                                               // [word][h][lane]
+    // scratch of the wave: [step][lane][8 words] of survivor bits + [word][h][lane] of decoded bits; OVL: two such halves
+    const size_t half_words = n_data_cap * 512 + (n_data_cap / 32 + 2) * 256;
+    uint32_t* const scr0 = reinterpret_cast<uint32_t*>(scratch + (size_t)wave * scratch_stride);
+    int buf = 0;
+    TbPending pend;
+    pend.active = false;
     const uint32_t k1 = 0x01010101u;
     uint32_t sel0 = 0x03020100u;                      // v_perm_b32 selector "every byte from the second source", kept in a register
     asm volatile("" : "+v"(sel0));
@@ -823,9 +845,59 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
         if (ROWS < 48 && enc_u >= 6) continue;                                      // (the host launches the 48-row instance when 64-QAM frames exist)
         const int sym_blk = blk_w / nw_u;
 
+        uint32_t* surv = scr0 + (OVL ? (size_t)buf * half_words : 0);
+        uint32_t* dbits = surv + n_data_cap * 512;
         uint32_t pm[64];
         int best[4] = { 0, 0, 0, 0 };
         int tt_u = 0, sym_u = 0, since_norm = 0;
+#define WR_DQ_PICKP(ST, LO, HI)                                                                           \
+        (__builtin_amdgcn_ubfe((((ST & 32) ? (HI) : (LO)) ^ 0x77777777u), (uint32_t)((ST & 31) ^ 3), 1u))
+        // six trace-back steps of the pending task (OVL); when a block of 96 steps is through its three decoded words per
+        // frame leave, when the last block is through the frames are finished (descrambling, bytes, CRC)
+        auto tb_group = [&]() __attribute__((always_inline)) {
+            const uint32_t* srow = pend.surv + ((size_t)(pend.blk * 96 + 6 * pend.grp) * 64 + lane) * 8;
+            uint32_t l0[6], u0[6], l1[6], u1[6], l2[6], u2[6], l3[6], u3[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const uint4* sp = reinterpret_cast<const uint4*>(srow + (size_t)k * 512);
+                const uint4 a = sp[0], b = sp[1];
+                l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
+            }
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const uint32_t v = __builtin_bitreverse32((uint32_t)pend.st[h]) >> 26;
+                pend.aw[h][2] = __builtin_amdgcn_alignbit(pend.aw[h][2], pend.aw[h][1], 26);
+                pend.aw[h][1] = __builtin_amdgcn_alignbit(pend.aw[h][1], pend.aw[h][0], 26);
+                pend.aw[h][0] = (pend.aw[h][0] << 6) | v;
+            }
+#pragma unroll
+            for (int q = 5; q >= 0; q--) {
+                const uint32_t h0 = WR_DQ_PICKP(pend.st[0], l0[q], u0[q]), h1 = WR_DQ_PICKP(pend.st[1], l1[q], u1[q]);
+                const uint32_t h2 = WR_DQ_PICKP(pend.st[2], l2[q], u2[q]), h3 = WR_DQ_PICKP(pend.st[3], l3[q], u3[q]);
+                pend.st[0] = (pend.st[0] >> 1) | (int)(h0 << 5);
+                pend.st[1] = (pend.st[1] >> 1) | (int)(h1 << 5);
+                pend.st[2] = (pend.st[2] >> 1) | (int)(h2 << 5);
+                pend.st[3] = (pend.st[3] >> 1) | (int)(h3 << 5);
+            }
+            if (--pend.grp < 0) {
+#pragma unroll
+                for (int w = 0; w < 3; w++)
+#pragma unroll
+                    for (int h = 0; h < 4; h++) { pend.dbits[(size_t)(pend.blk * 3 + w) * 256 + 64 * h + lane] = pend.aw[h][w]; pend.aw[h][w] = 0u; }
+                pend.grp = 15;
+                if (--pend.blk < 0) {
+                    __threadfence_block();
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const uint32_t slot = pend.slot[h];
+                        if (slot != 0xffffffffu)
+                            finish_frame<256>(pend.dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
+                                              ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags, ft);
+                    }
+                    pend.active = false;
+                }
+            }
+        };
         // one group of six trellis steps; `first`: the group without comparisons (steps 0..5)
         auto group = [&](auto first_tag, const int tg) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -955,9 +1027,11 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
                 }
             }
             tt_u += 6;
+            if (OVL && pend.active) tb_group();
         };
         group(std::true_type{}, 0);
         for (int tg = 6; tg < n_max; tg += 6) group(std::false_type{}, tg);
+        if (OVL) { while (pend.active) tb_group(); }      // a pending task with a longer trellis than this one: the rest of it
         __threadfence_block();
         // ---- traceback of the four frames of a lane: 32 decoded bits per word, words stored [word][h][lane].  A step of
         //      a frame reads ITS two survivor words of the row (compile-time positions), picks the half by bit 5 of the
@@ -1001,6 +1075,23 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
                         }
                     }
                 }
+            }
+            if (OVL && n_fast > 0) {
+                // the blocks of 96 steps are walked back while the wave's next task runs (or right after the task loop)
+                pend.active = true;
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    pend.st[h] = st[h];
+                    pend.slot[h] = n_data[h] > 0 ? slot_of[h] : 0xffffffffu;
+#pragma unroll
+                    for (int w = 0; w < 3; w++) pend.aw[h][w] = 0u;
+                }
+                pend.blk = n_fast / 96 - 1;
+                pend.grp = 15;
+                pend.surv = surv;
+                pend.dbits = dbits;
+                buf ^= 1;
+                continue;
             }
             for (int blk = n_fast / 96 - 1; blk >= 0; blk--) {
                 // the 96 decoded bits of the block per frame: the groups come from the top step down, so every six steps the
@@ -1051,6 +1142,54 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
             }
         }
     }
+    if (OVL) {
+        // the wave's last deferred task: walked back on its own (tb_group lives inside the task loop: the same steps here)
+        while (pend.active) {
+            const uint32_t* srow = pend.surv + ((size_t)(pend.blk * 96 + 6 * pend.grp) * 64 + lane) * 8;
+            uint32_t l0[6], u0[6], l1[6], u1[6], l2[6], u2[6], l3[6], u3[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const uint4* sp = reinterpret_cast<const uint4*>(srow + (size_t)k * 512);
+                const uint4 a = sp[0], b = sp[1];
+                l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
+            }
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const uint32_t v = __builtin_bitreverse32((uint32_t)pend.st[h]) >> 26;
+                pend.aw[h][2] = __builtin_amdgcn_alignbit(pend.aw[h][2], pend.aw[h][1], 26);
+                pend.aw[h][1] = __builtin_amdgcn_alignbit(pend.aw[h][1], pend.aw[h][0], 26);
+                pend.aw[h][0] = (pend.aw[h][0] << 6) | v;
+            }
+#pragma unroll
+            for (int q = 5; q >= 0; q--) {
+                const uint32_t h0 = WR_DQ_PICKP(pend.st[0], l0[q], u0[q]), h1 = WR_DQ_PICKP(pend.st[1], l1[q], u1[q]);
+                const uint32_t h2 = WR_DQ_PICKP(pend.st[2], l2[q], u2[q]), h3 = WR_DQ_PICKP(pend.st[3], l3[q], u3[q]);
+                pend.st[0] = (pend.st[0] >> 1) | (int)(h0 << 5);
+                pend.st[1] = (pend.st[1] >> 1) | (int)(h1 << 5);
+                pend.st[2] = (pend.st[2] >> 1) | (int)(h2 << 5);
+                pend.st[3] = (pend.st[3] >> 1) | (int)(h3 << 5);
+            }
+            if (--pend.grp < 0) {
+#pragma unroll
+                for (int w = 0; w < 3; w++)
+#pragma unroll
+                    for (int h = 0; h < 4; h++) { pend.dbits[(size_t)(pend.blk * 3 + w) * 256 + 64 * h + lane] = pend.aw[h][w]; pend.aw[h][w] = 0u; }
+                pend.grp = 15;
+                if (--pend.blk < 0) {
+                    __threadfence_block();
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const uint32_t slot = pend.slot[h];
+                        if (slot != 0xffffffffu)
+                            finish_frame<256>(pend.dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
+                                              ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags, ft);
+                    }
+                    pend.active = false;
+                }
+            }
+        }
+    }
+#undef WR_DQ_PICKP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1324,16 +1463,15 @@ extern "C" hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_
 extern "C" hipError_t wr_launch_decode_q(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                                          const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
                                          size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
-                                         const uint32_t* perm, uint32_t n_virtual, int has_64qam)
+                                         const uint32_t* perm, uint32_t n_virtual, int has_64qam, int overlap)
 {
     if (n_slots == 0 || n_waves == 0) return hipSuccess;
     if (!perm) n_virtual = n_slots;
-    if (has_64qam)
-        hipLaunchKernelGGL(wr::decode_q_kernel<48>, dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
-                           psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual);
-    else
-        hipLaunchKernelGGL(wr::decode_q_kernel<32>, dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, frames, hbits, psdu,
-                           psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual);
+#define WR_LAUNCH_Q(ROWS, OVL) hipLaunchKernelGGL((wr::decode_q_kernel<ROWS, OVL>), dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, \
+                                                  frames, hbits, psdu, psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual)
+    if (has_64qam) { if (overlap) WR_LAUNCH_Q(48, true); else WR_LAUNCH_Q(48, false); }
+    else           { if (overlap) WR_LAUNCH_Q(32, true); else WR_LAUNCH_Q(32, false); }
+#undef WR_LAUNCH_Q
     return hipGetLastError();
 }
 

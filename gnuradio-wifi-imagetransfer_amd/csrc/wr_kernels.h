@@ -73,7 +73,7 @@ hipError_t wr_launch_decode(hipStream_t st, uint32_t n_slots, uint32_t max_sym, 
 hipError_t wr_launch_decode_q(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,
                               const uint32_t* hbits, uint8_t* psdu, uint32_t psdu_stride, uint8_t* scratch,
                               size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
-                              const uint32_t* perm, uint32_t n_virtual, int has_64qam);
+                              const uint32_t* perm, uint32_t n_virtual, int has_64qam, int overlap);
 hipError_t wr_launch_decode_perm(hipStream_t st, uint32_t n_slots, uint32_t max_sym, const wifirx_frame* frames,
                                  uint32_t psdu_stride, const uint32_t* starts8, uint32_t* cursor8, uint32_t* perm);
 hipError_t wr_launch_decode_small(hipStream_t st, uint32_t n_slots, uint32_t max_sym, wifirx_frame* frames,

@@ -59,6 +59,7 @@ def test_random_frames_four_frames_per_lane_decoder(monkeypatch):
     import parity_campaign as pc
     monkeypatch.setenv("WIFIRX_DECODE_Q", "1")
     monkeypatch.setenv("WIFIRX_DECODE_FPW", "256")
+    monkeypatch.setenv("WIFIRX_DECODE_OVL", "1")          # trace-back overlapped with the next task (uniform tasks are deferred, others not)
     res = pc.run(20000, 306, equalisers=(0, 1), decode_small_max=0)
     _record("frames_seed306_four_frames_per_lane_decoder", res)
     for name, v in res["equalisers"].items():

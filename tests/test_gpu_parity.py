@@ -89,15 +89,19 @@ def test_decode_mac_full_waves(capi, orc, monkeypatch, encoding, plen, snr):
         assert ((o["frames"]["flags"] & orc.F_CRC_OK) != 0).all() and np.array_equal(r["psdu"][:, :plen], tx.psdu)
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("encoding,plen,snr", [(2, 294, 25.0), (2, 294, 5.0), (0, 60, 6.0), (7, 294, 19.5), (5, 100, 13.0), (4, 333, 11.0)])
-def test_decode_mac_four_frames_per_lane(capi, orc, monkeypatch, encoding, plen, snr):
+def test_decode_mac_four_frames_per_lane(capi, orc, monkeypatch, encoding, plen, snr, overlap):
     """decode_q_kernel (four frames per lane, byte path metrics, 256 frames per wave: what batches of a million frames
     take) forced onto a small batch with every frame position of its waves filled: byte for byte the oracle's PSDUs, at
     every constellation incl. the 48-row instance for 64-QAM, also where the channel leaves bit errors and ties."""
     monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "0")
     monkeypatch.setenv("WIFIRX_DECODE_Q", "1")
     monkeypatch.setenv("WIFIRX_DECODE_FPW", "256")
-    n = 600                                                   # two full waves + one with 88 frames
+    # overlap = 1: the trace-back of a task runs interleaved with the add-compare-select of the wave's next task (what a
+    # million-frame batch takes); 1400 frames = 6 tasks on 3 waves: deferred, interleaved and drained trace-backs all occur
+    monkeypatch.setenv("WIFIRX_DECODE_OVL", str(overlap))
+    n = 1400 if overlap else 600                              # full waves + one partly filled
     iq, slot_len, tx = make_slots(n, encoding, psdu_len=plen, snr_db=snr, seed=300 + encoding)
     rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=0)
     r = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=384)
