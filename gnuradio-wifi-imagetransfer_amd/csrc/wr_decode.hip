@@ -778,6 +778,59 @@ struct TbPending {
     uint32_t* dbits;
 };
 
+// Six trace-back steps of a pending task (decode_q_kernel, OVL).  When a block of 96 steps is through, its three decoded
+// words per frame leave; when the last block is through, the frames are finished (descrambling, bytes, CRC).
+#define WR_DQ_PICKP(ST, LO, HI)                                                                           \
+    (__builtin_amdgcn_ubfe((((ST & 32) ? (HI) : (LO)) ^ 0x77777777u), (uint32_t)((ST & 31) ^ 3), 1u))
+__device__ __forceinline__ void tb_pending_group(TbPending& pend, int lane, wifirx_frame* __restrict__ frames,
+                                                 uint8_t* __restrict__ psdu_all, uint32_t psdu_stride, const FinishTables& ft)
+{
+    const uint32_t* srow = pend.surv + ((size_t)(pend.blk * 96 + 6 * pend.grp) * 64 + lane) * 8;
+    // (one array per word position: a select between two elements of ONE array becomes an indexed access in scratch memory)
+    uint32_t l0[6], u0[6], l1[6], u1[6], l2[6], u2[6], l3[6], u3[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint4* sp = reinterpret_cast<const uint4*>(srow + (size_t)k * 512);
+        const uint4 a = sp[0], b = sp[1];
+        l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        const uint32_t v = __builtin_bitreverse32((uint32_t)pend.st[h]) >> 26;      // u_(t-5) .. u_t, oldest in bit 0
+        pend.aw[h][2] = __builtin_amdgcn_alignbit(pend.aw[h][2], pend.aw[h][1], 26);  // the triple moves UP by six ...
+        pend.aw[h][1] = __builtin_amdgcn_alignbit(pend.aw[h][1], pend.aw[h][0], 26);
+        pend.aw[h][0] = (pend.aw[h][0] << 6) | v;                                      // ... the older steps' bits enter below
+    }
+#pragma unroll
+    for (int q = 5; q >= 0; q--) {
+        const uint32_t h0 = WR_DQ_PICKP(pend.st[0], l0[q], u0[q]), h1 = WR_DQ_PICKP(pend.st[1], l1[q], u1[q]);
+        const uint32_t h2 = WR_DQ_PICKP(pend.st[2], l2[q], u2[q]), h3 = WR_DQ_PICKP(pend.st[3], l3[q], u3[q]);
+        pend.st[0] = (pend.st[0] >> 1) | (int)(h0 << 5);
+        pend.st[1] = (pend.st[1] >> 1) | (int)(h1 << 5);
+        pend.st[2] = (pend.st[2] >> 1) | (int)(h2 << 5);
+        pend.st[3] = (pend.st[3] >> 1) | (int)(h3 << 5);
+    }
+    if (--pend.grp < 0) {
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+#pragma unroll
+            for (int h = 0; h < 4; h++) { pend.dbits[(size_t)(pend.blk * 3 + w) * 256 + 64 * h + lane] = pend.aw[h][w]; pend.aw[h][w] = 0u; }
+        pend.grp = 15;
+        if (--pend.blk < 0) {
+            __threadfence_block();
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const uint32_t slot = pend.slot[h];
+                if (slot != 0xffffffffu)
+                    finish_frame<256>(pend.dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
+                                      ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags, ft);
+            }
+            pend.active = false;
+        }
+    }
+}
+#undef WR_DQ_PICKP
+
 template <int ROWS, bool OVL>        // LDS rows per wave: 32 (rates up to 16-QAM: 8 staged words x 4), 48 (64-QAM: one symbol of 12 words)
 __global__ __launch_bounds__(256, OVL ? 2 : (ROWS == 32 ? 4 : 3))
 void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
@@ -850,54 +903,6 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
         uint32_t pm[64];
         int best[4] = { 0, 0, 0, 0 };
         int tt_u = 0, sym_u = 0, since_norm = 0;
-#define WR_DQ_PICKP(ST, LO, HI)                                                                           \
-        (__builtin_amdgcn_ubfe((((ST & 32) ? (HI) : (LO)) ^ 0x77777777u), (uint32_t)((ST & 31) ^ 3), 1u))
-        // six trace-back steps of the pending task (OVL); when a block of 96 steps is through its three decoded words per
-        // frame leave, when the last block is through the frames are finished (descrambling, bytes, CRC)
-        auto tb_group = [&]() __attribute__((always_inline)) {
-            const uint32_t* srow = pend.surv + ((size_t)(pend.blk * 96 + 6 * pend.grp) * 64 + lane) * 8;
-            uint32_t l0[6], u0[6], l1[6], u1[6], l2[6], u2[6], l3[6], u3[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const uint4* sp = reinterpret_cast<const uint4*>(srow + (size_t)k * 512);
-                const uint4 a = sp[0], b = sp[1];
-                l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
-            }
-#pragma unroll
-            for (int h = 0; h < 4; h++) {
-                const uint32_t v = __builtin_bitreverse32((uint32_t)pend.st[h]) >> 26;
-                pend.aw[h][2] = __builtin_amdgcn_alignbit(pend.aw[h][2], pend.aw[h][1], 26);
-                pend.aw[h][1] = __builtin_amdgcn_alignbit(pend.aw[h][1], pend.aw[h][0], 26);
-                pend.aw[h][0] = (pend.aw[h][0] << 6) | v;
-            }
-#pragma unroll
-            for (int q = 5; q >= 0; q--) {
-                const uint32_t h0 = WR_DQ_PICKP(pend.st[0], l0[q], u0[q]), h1 = WR_DQ_PICKP(pend.st[1], l1[q], u1[q]);
-                const uint32_t h2 = WR_DQ_PICKP(pend.st[2], l2[q], u2[q]), h3 = WR_DQ_PICKP(pend.st[3], l3[q], u3[q]);
-                pend.st[0] = (pend.st[0] >> 1) | (int)(h0 << 5);
-                pend.st[1] = (pend.st[1] >> 1) | (int)(h1 << 5);
-                pend.st[2] = (pend.st[2] >> 1) | (int)(h2 << 5);
-                pend.st[3] = (pend.st[3] >> 1) | (int)(h3 << 5);
-            }
-            if (--pend.grp < 0) {
-#pragma unroll
-                for (int w = 0; w < 3; w++)
-#pragma unroll
-                    for (int h = 0; h < 4; h++) { pend.dbits[(size_t)(pend.blk * 3 + w) * 256 + 64 * h + lane] = pend.aw[h][w]; pend.aw[h][w] = 0u; }
-                pend.grp = 15;
-                if (--pend.blk < 0) {
-                    __threadfence_block();
-#pragma unroll
-                    for (int h = 0; h < 4; h++) {
-                        const uint32_t slot = pend.slot[h];
-                        if (slot != 0xffffffffu)
-                            finish_frame<256>(pend.dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
-                                              ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags, ft);
-                    }
-                    pend.active = false;
-                }
-            }
-        };
         // one group of six trellis steps; `first`: the group without comparisons (steps 0..5)
         auto group = [&](auto first_tag, const int tg) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -1027,11 +1032,11 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
                 }
             }
             tt_u += 6;
-            if (OVL && pend.active) tb_group();
+            if (OVL && pend.active) tb_pending_group(pend, lane, frames, psdu_all, psdu_stride, ft);
         };
         group(std::true_type{}, 0);
         for (int tg = 6; tg < n_max; tg += 6) group(std::false_type{}, tg);
-        if (OVL) { while (pend.active) tb_group(); }      // a pending task with a longer trellis than this one: the rest of it
+        if (OVL) { while (pend.active) tb_pending_group(pend, lane, frames, psdu_all, psdu_stride, ft); }      // a pending task with a longer trellis: the rest of it
         __threadfence_block();
         // ---- traceback of the four frames of a lane: 32 decoded bits per word, words stored [word][h][lane].  A step of
         //      a frame reads ITS two survivor words of the row (compile-time positions), picks the half by bit 5 of the
@@ -1142,54 +1147,7 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
             }
         }
     }
-    if (OVL) {
-        // the wave's last deferred task: walked back on its own (tb_group lives inside the task loop: the same steps here)
-        while (pend.active) {
-            const uint32_t* srow = pend.surv + ((size_t)(pend.blk * 96 + 6 * pend.grp) * 64 + lane) * 8;
-            uint32_t l0[6], u0[6], l1[6], u1[6], l2[6], u2[6], l3[6], u3[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const uint4* sp = reinterpret_cast<const uint4*>(srow + (size_t)k * 512);
-                const uint4 a = sp[0], b = sp[1];
-                l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
-            }
-#pragma unroll
-            for (int h = 0; h < 4; h++) {
-                const uint32_t v = __builtin_bitreverse32((uint32_t)pend.st[h]) >> 26;
-                pend.aw[h][2] = __builtin_amdgcn_alignbit(pend.aw[h][2], pend.aw[h][1], 26);
-                pend.aw[h][1] = __builtin_amdgcn_alignbit(pend.aw[h][1], pend.aw[h][0], 26);
-                pend.aw[h][0] = (pend.aw[h][0] << 6) | v;
-            }
-#pragma unroll
-            for (int q = 5; q >= 0; q--) {
-                const uint32_t h0 = WR_DQ_PICKP(pend.st[0], l0[q], u0[q]), h1 = WR_DQ_PICKP(pend.st[1], l1[q], u1[q]);
-                const uint32_t h2 = WR_DQ_PICKP(pend.st[2], l2[q], u2[q]), h3 = WR_DQ_PICKP(pend.st[3], l3[q], u3[q]);
-                pend.st[0] = (pend.st[0] >> 1) | (int)(h0 << 5);
-                pend.st[1] = (pend.st[1] >> 1) | (int)(h1 << 5);
-                pend.st[2] = (pend.st[2] >> 1) | (int)(h2 << 5);
-                pend.st[3] = (pend.st[3] >> 1) | (int)(h3 << 5);
-            }
-            if (--pend.grp < 0) {
-#pragma unroll
-                for (int w = 0; w < 3; w++)
-#pragma unroll
-                    for (int h = 0; h < 4; h++) { pend.dbits[(size_t)(pend.blk * 3 + w) * 256 + 64 * h + lane] = pend.aw[h][w]; pend.aw[h][w] = 0u; }
-                pend.grp = 15;
-                if (--pend.blk < 0) {
-                    __threadfence_block();
-#pragma unroll
-                    for (int h = 0; h < 4; h++) {
-                        const uint32_t slot = pend.slot[h];
-                        if (slot != 0xffffffffu)
-                            finish_frame<256>(pend.dbits + 64 * h + lane, frames[slot].psdu_len, psdu_all + (size_t)slot * psdu_stride,
-                                              ((reinterpret_cast<uintptr_t>(psdu_all) | psdu_stride) & 3) == 0, frames + slot, frames[slot].flags, ft);
-                    }
-                    pend.active = false;
-                }
-            }
-        }
-    }
-#undef WR_DQ_PICKP
+    if (OVL) { while (pend.active) tb_pending_group(pend, lane, frames, psdu_all, psdu_stride, ft); }      // the wave's last deferred task: on its own
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,8 +1,8 @@
 // wr_kernels.hip -- HIP kernels of the wifirx receive chain for gfx950 (MI355X, CDNA4).
 //
-// One wavefront (64 lanes) owns four frames.  Preamble phase: the whole wave works on one slot (lane <-> sample while
-// scanning for the short preamble) or on a pair of frames (the LTS search on the int8 matrix cores, wr_quad.h); symbol
-// phase: row f = lanes 16f..16f+15 owns frame f, lane r of the row holds bins r + 16 j.  The per-frame state of the
+// One wavefront (64 lanes) owns four frames.  Preamble phase: the four slots are scanned for the short preamble in lock
+// step (row f = slot f, lane <-> sample of a 16-sample block), then pairs of frames go through the LTS search (int8 matrix
+// cores, wr_quad.h); symbol phase: row f = lanes 16f..16f+15 owns frame f, lane r of the row holds bins r + 16 j.  The per-frame state of the
 // reference's frame_equalizer (d_er, previous pilots, channel estimate H) lives in registers and wave-private LDS for
 // the whole frame, so the symbols of a frame are walked in order by the same wave and a million frames run side by
 // side.  The whole chain is fused: the samples of a slot are read from HBM once, the only HBM writes are the
@@ -27,16 +27,14 @@
 #ifndef WR_ABLATE
 #define WR_ABLATE 0
 #endif
-#ifndef WR_DETECT_AHEAD
-#define WR_DETECT_AHEAD 4      // tiles of 64 samples whose loads detect_first issues up front
-#endif
 
 namespace wr {
 
 // ---------------------------------------------------------------------------------------------
-// detect phase (a1 + a2).  One tile = 64 consecutive samples, lane <-> sample; the window sums
-// follow the blocked scheme of the spec (section 4.2): Kogge-Stone prefix H / exclusive suffix T inside
-// blocks of 16 lanes (DPP row shifts), block totals and tails of the 3-4 previous blocks.
+// detect phase (a1 + a2), stream form (stream_detect_kernel): one tile = 64 consecutive samples, lane <-> sample; the
+// window sums follow the blocked scheme of the spec (section 4.2): Kogge-Stone prefix H / exclusive suffix T inside blocks of
+// 16 lanes (DPP row shifts), block totals and tails of the 3-4 previous blocks fetched across rows.  The batch kernel
+// uses detect_quad() below.
 struct DetectState {       // what a tile needs from the tile before it
     float Hr, Hi, Hp, Tr, Ti, Tp;
 };
@@ -95,14 +93,6 @@ __device__ __forceinline__ uint64_t detect_tile(const float2* __restrict__ x, lo
     return detect_tile_core(load_sample(x, n, n_samp), load_sample(x, n - 16, n_samp), n_samp, n0, thr, lane, ps, Ar, Ai);
 }
 
-// positions where c > thr held for min_plateau+1 consecutive samples ending there
-__device__ __forceinline__ uint64_t plateau_hits(uint64_t mask, uint64_t prev_mask, int min_plateau)
-{
-    uint64_t hit = mask;
-    for (int j = 1; j <= min_plateau; j++) hit &= (mask << j) | (prev_mask >> (64 - j));
-    return hit;
-}
-
 // first sync_short trigger of each of the FOUR slots of a wave, in lock step (batch mode): row f = lanes 16f..16f+15 walks
 // slot f in blocks of 16 samples, lane r of the row <-> sample 16m + r of block m.  The spec's 16-sample blocks (rule 3) are
 // then exactly a DPP row: prefix H and suffix T are row scans, the block total B = H[15] is a row broadcast, and what a
@@ -117,7 +107,9 @@ struct DetectQuadState {
     float Br[2], Bi[2], Bp[3];    // totals of blocks m-1, m-2 (, m-3)
 };
 
+#ifndef WR_DQ_GROUP
 #define WR_DQ_GROUP 4             // blocks per request group
+#endif
 
 __device__ __forceinline__ void detect_quad_load(const float2* __restrict__ x, int n_samp, int m0, int r, c32 (&v)[WR_DQ_GROUP])
 {

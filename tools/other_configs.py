@@ -27,7 +27,8 @@ CASES = [   # name, encoding, PSDU bytes, slot length
 def main():
     n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
     res = []
-    for name, enc, plen, slot_len in (CASES if not os.environ.get("WIFIRX_ONLY_EQ") else []):
+    only = os.environ.get("WIFIRX_ONLY_CASE")          # A/B runs: one geometry, demod only
+    for name, enc, plen, slot_len in ((CASES if only is None else [CASES[int(only)]]) if not os.environ.get("WIFIRX_ONLY_EQ") else []):
         n_sym = txgen.n_sym_for(plen, enc)
         n_bpsc = txgen.RATE_TABLE[enc][0]
         tx = txgen.encode_psdus(txgen.make_psdus(256, plen, seed=5), enc)
@@ -57,6 +58,9 @@ def main():
                     "roofline_frac": bpf * n_frames / (ms * 1e-3) / 8e12, "demod_with_planes_ms": ms_planes, "decode_mac_ms": dec_ms,
                     "crc_ok": int(((fr["flags"] & capi.F_CRC_OK) != 0).sum())})
         rx.free_out(dev); slots.free(); rx.close()
+    if only is not None:
+        print(json.dumps({"cases": res, "equalisers": []}))
+        return
     # several rates in one batch (decode_mac's per-lane look-up kernel): QPSK-1/2 and 16-QAM-3/4 frames alternate
     if not os.environ.get("WIFIRX_ONLY_EQ"):
         plen, slot_len = 294, 4608
