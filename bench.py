@@ -115,8 +115,6 @@ def collective_info(dist, torch, backend, rank, local_rank, world, coll_dev):
     """What a reader of the JSON line needs to check that the collective library really saw N ranks: the backend as
     torch.distributed reports it, the RCCL version (torch.cuda.nccl.version(): RCCL on ROCm), the rank count as a
     collective itself counts it (all-reduce of ones), and which host / device every rank ran on."""
-    if world <= 1:
-        return None
     ones = torch.ones(1, dtype=torch.int64, device=coll_dev)
     dist.all_reduce(ones)
     me = {"rank": rank, "host": socket.gethostname(), "local_rank": local_rank, "pid": os.getpid()}
@@ -166,7 +164,15 @@ def main():
         torch.cuda.set_device(local_rank)
     dist = None
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    # WIFIRX_BENCH_FORCE_DIST=1: run the multi-rank code path with ONE rank (process group, barriers, RCCL all-reduce /
+    # all-gather on the library's stream) -- the only way RCCL itself can execute on the one-GPU build pool
+    use_dist = world > 1 or (os.environ.get("WIFIRX_BENCH_FORCE_DIST") == "1" and not stub)
+    if use_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if use_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -215,7 +221,7 @@ def main():
     if os.environ.get("WIFIRX_BENCH_NOIDX"):                     # experiment switch: what the four byte stores per symbol cost
         out.idx = None
     gather = None
-    if world > 1 and want_pdus:
+    if use_dist and want_pdus:
         gather = wdist.ChunkedPduGather(n_frames, PSDU_STRIDE, args.gather_chunks, coll_dev)
     lib_stream = torch.cuda.ExternalStream(rx.stream_ptr())      # the handle's own HIP stream, as torch sees it
     # the zero fills above ran on torch's stream, the library launches on its own: order them once
@@ -263,7 +269,7 @@ def main():
         return (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -277,7 +283,7 @@ def main():
     t_own = time.perf_counter() - t0          # this rank alone, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -287,12 +293,12 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     kernel_ms_avg = kernel_ms / args.steps
     per_rank = [{"rank": rank, "kernel_ms": kernel_ms_avg, "gsamples_per_s": float(n_frames) * SLOT_LEN * args.steps / t_own / 1e9}]
-    if world > 1:
+    if use_dist:
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
 
-    coll = collective_info(dist, torch, backend, rank, local_rank, world, coll_dev)
+    coll = collective_info(dist, torch, backend, rank, local_rank, world, coll_dev) if use_dist else None
 
     # ---- the leg behind the hot path: decode_mac (+ RCCL all-gather of the PDUs), timed on its own ----
     pdu_leg = None
@@ -337,10 +343,10 @@ def main():
         pdu_leg = {"decode_mac_ms": float(np.median(dec_ms)),
                    "demod_with_planes_ms": demod_planes_ms, "decode_mac_from_idx_ms": dec_from_idx_ms,
                    "demod_planes_only_ms": demod_pdu_only_ms,
-                   "all_gather_ms": ag_alone, "all_gather_exposed_ms": float(np.median(ag_ms)) if world > 1 else None,
+                   "all_gather_ms": ag_alone, "all_gather_exposed_ms": float(np.median(ag_ms)) if use_dist else None,
                    "gather_chunks": gather.n_chunks if gather is not None else None,
                    "ms_per_step": leg, "psdu_stride": PSDU_STRIDE,
-                   "gathered_bytes_per_rank": (PSDU_STRIDE + 32) * n_frames * world if world > 1 else None,
+                   "gathered_bytes_per_rank": (PSDU_STRIDE + 32) * n_frames * world if use_dist else None,
                    "note": "decode_mac on the device; N > 1: RCCL all_gather_into_tensor of PSDUs and frame records, chunk c "
                            "overlapping decode_mac of chunk c+1 (all_gather_exposed_ms = what is left after the last decode); "
                            "not in `value`"}
@@ -554,7 +560,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     rx.close()
@@ -595,7 +601,7 @@ def run_stub(args, rank, world, dist, wdist, torch):
         elapsed = float(tmax.item())
     ok = True
     n_pdus = n_frames
-    coll = collective_info(dist, torch, "gloo", rank, int(os.environ.get("LOCAL_RANK", "0")), world, "cpu")
+    coll = collective_info(dist, torch, "gloo", rank, int(os.environ.get("LOCAL_RANK", "0")), world, "cpu") if world > 1 else None
     if gather is not None:
         p_t = torch.from_numpy(psdu)
         f_t = torch.from_numpy(frames.view(np.uint8).reshape(n_frames, 32))

@@ -20,6 +20,9 @@
 
 namespace wr {
 
+#ifndef WR_GLOBAL_SAMPLE_LOADS
+#define WR_GLOBAL_SAMPLE_LOADS 1
+#endif
 #define WR_QLDS_SCRATCH 768
 #define WR_QLDS_H       (WR_QLDS_SCRATCH)            // 4 x 64 float2: channel estimate, lane-private slots
 #define WR_QLDS_TW      (WR_QLDS_H + 512)              // 6 x 16 float2: stage-1/2 twiddles by row lane
@@ -29,6 +32,19 @@ namespace wr {
 #define WR_QLDS_FLOATS  (WR_QLDS_STAT + 16)          // per wave; the preamble phase uses the first 1536 floats for two frames' samples
 #define WR_QLDS_DH      (WR_QLDS_FLOATS)             // COMB only: 4 x 64 float2, the running estimate d_H
 #define WR_QLDS_FLOATS_EQ(EQ) (WR_QLDS_FLOATS + ((EQ) == WIFIRX_EQ_COMB ? 512 : 0))
+
+// a sample through the global-memory path: the symbol loop's sample pointer is rebuilt from lane exchanges, which hides
+// its address space from the compiler (it would take the flat path, which also counts on the LDS counter)
+typedef float wr_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 load_global_f2(const float2* p)
+{
+#if WR_GLOBAL_SAMPLE_LOADS && defined(__HIP_DEVICE_COMPILE__)
+    const wr_f2 v = *reinterpret_cast<const __attribute__((address_space(1))) wr_f2*>(reinterpret_cast<uintptr_t>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
 
 __device__ __forceinline__ c32 load_sample(const float2* __restrict__ x, long n, long n_samp)
 {
@@ -48,7 +64,7 @@ __device__ __forceinline__ c32 load_y(const float2* __restrict__ xb, int m, int 
     mc = mc > m_lo ? mc : m_lo;
     const bool ok = (m >= m_lo) && (m < m_hi);
     float2 t = make_float2(0.0f, 0.0f);
-    if (m_hi > m_lo) t = xb[mc];
+    if (m_hi > m_lo) t = load_global_f2(xb + mc);
     return { ok ? t.x : 0.0f, ok ? t.y : 0.0f };
 }
 
@@ -928,7 +944,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 // numbers that no output sees -- cheaper than zeroing eight registers per symbol for them
                 const float2* p = xb + ((act ? off0 : 0) + r);
 #pragma unroll
-                for (int j = 0; j < 4; j++) { const float2 t = p[16 * j]; cur[j] = { t.x, t.y }; }
+                for (int j = 0; j < 4; j++) { const float2 t = load_global_f2(p + 16 * j); cur[j] = { t.x, t.y }; }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) cur[j] = load_y(xb, off0 + r + 16 * j, m_lo, act ? m_hi : 0);
