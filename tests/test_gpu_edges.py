@@ -142,3 +142,39 @@ def test_slots_of_unequal_length(orc):
         assert np.array_equal(r["carrier"][k], o["eq"][0]), k
         n_ok += int((o["frames"]["flags"][0] & orc.F_COMPLETE) != 0)
     assert n_ok == len(encs)
+
+
+@pytest.mark.parametrize("encoding", [0, 2, 4, 7])
+def test_demod_with_minimally_aligned_output_buffers(orc, encoding):
+    """The C ABI promises nothing about the callers' output buffers beyond the alignment of their element types: LLRs on
+    a 4-byte, equalised points on an 8-byte, decisions on a 1-byte boundary must give the same values as aligned
+    buffers (the kernel's wide stores -- 16 bytes per 16-QAM carrier -- then simply split)."""
+    from helpers import make_slots
+    from wifirx import capi
+    C = capi.C
+    n = 96
+    iq, slot_len, tx = make_slots(n, encoding, snr_db=27.0, seed=31 + encoding, psdu_len=120)
+    n_bpsc = (1, 1, 2, 2, 4, 4, 6, 6)[encoding]
+    per = tx.n_sym * 48
+    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=n_bpsc, want_carrier=True)
+    d_iq = rx.alloc(iq.nbytes).upload(iq)
+    d_fr, d_idx = rx.alloc(n * 32), rx.alloc(n * per + 64)
+    d_llr, d_car = rx.alloc(n * per * n_bpsc * 4 + 64), rx.alloc(n * per * 8 + 64)
+    for b in (d_fr, d_idx, d_llr, d_car):
+        b.upload(np.zeros(b.nbytes, np.uint8))
+    out = capi.Out(d_fr.ptr, d_idx.ptr + 3, d_llr.ptr + 4, d_car.ptr + 8, None, 0, 1, None)
+    rx._check(capi.lib().wifirx_demod_batch(rx._h, d_iq.ptr, 1, slot_len, n, C.byref(out)))
+    rx.sync()
+    fr = d_fr.download(capi.FRAME_DTYPE, n)
+    idx = d_idx.download(np.uint8, n * per + 3)[3:].reshape(n, per)
+    llr = d_llr.download(np.float32, n * per * n_bpsc + 1)[1:].reshape(n, per * n_bpsc)
+    car = d_car.download(np.complex64, n * per + 1)[1:].reshape(n, per)
+    prm = orc.make_params(max_sym=tx.n_sym, llr_bits=n_bpsc)
+    o = orc.demod_batch(iq, slot_len, prm, want_eq=True)
+    assert np.array_equal(fr, o["frames"]) and (fr["flags"] & capi.F_COMPLETE).all()
+    assert np.array_equal(idx, o["idx"].reshape(n, per))
+    assert np.array_equal(llr, o["llr"].reshape(n, per * n_bpsc))
+    assert np.array_equal(car, o["eq"].reshape(n, per))
+    for b in (d_iq, d_fr, d_idx, d_llr, d_car):
+        b.free()
+    rx.close()
