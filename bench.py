@@ -68,7 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline, host_path and variant legs")
     ap.add_argument("--decode", action="store_true", help="put decode_mac (and the all-gather) INSIDE every timed step")
     ap.add_argument("--pdu-steps", type=int, default=2, help="steps of the separate decode_mac + all-gather leg (0 = skip)")
-    ap.add_argument("--gather-chunks", type=int, default=2, help="frame ranges the PDU all-gather is cut into (N > 1)")
+    ap.add_argument("--gather-chunks", type=int, default=0,
+                    help="frame ranges the PDU all-gather is cut into (N > 1); 0 = as many as keep every range on decode_mac's "
+                         "fastest kernel (>= 600 000 frames per range: one range for 1 M frames)")
     ap.add_argument("--host-samples", type=int, default=96_000_000, help="samples pushed through work() in the host_path leg")
     return ap.parse_args(argv)
 
@@ -222,7 +224,11 @@ def main():
         out.idx = None
     gather = None
     if use_dist and want_pdus:
-        gather = wdist.ChunkedPduGather(n_frames, PSDU_STRIDE, args.gather_chunks, coll_dev)
+        # decode_mac's four-frames-per-lane kernel takes ranges of >= 600 000 frames (12.0 ms per 1 M frames; two ranges of
+        # 500 000 on the two-frames-per-lane kernel: 14.1 ms): overlapping the exchange with the next range's decode pays only
+        # when the ranges stay that long
+        n_chunks = args.gather_chunks if args.gather_chunks > 0 else max(1, n_frames // 600000)
+        gather = wdist.ChunkedPduGather(n_frames, PSDU_STRIDE, n_chunks, coll_dev)
     lib_stream = torch.cuda.ExternalStream(rx.stream_ptr())      # the handle's own HIP stream, as torch sees it
     # the zero fills above ran on torch's stream, the library launches on its own: order them once
     torch.cuda.synchronize()
@@ -584,7 +590,7 @@ def run_stub(args, rank, world, dist, wdist, torch):
         psdu[:, 1:5] = (k[:, None] >> (8 * np.arange(4))) & 255
         return 0.0
 
-    gather = wdist.ChunkedPduGather(n_frames, PSDU_STRIDE, args.gather_chunks, "cpu") if world > 1 else None
+    gather = wdist.ChunkedPduGather(n_frames, PSDU_STRIDE, args.gather_chunks if args.gather_chunks > 0 else 2, "cpu") if world > 1 else None
     for _ in range(args.warmup):
         step()
     if world > 1:
