@@ -20,9 +20,6 @@
 
 namespace wr {
 
-#ifndef WR_QAM64_WIDE_STORES
-#define WR_QAM64_WIDE_STORES 1
-#endif
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
@@ -39,7 +36,6 @@ namespace wr {
 // a sample through the global-memory path: the symbol loop's sample pointer is rebuilt from lane exchanges, which hides
 // its address space from the compiler (it would take the flat path, which also counts on the LDS counter)
 typedef float wr_f2 __attribute__((ext_vector_type(2)));
-typedef float wr_f4u __attribute__((ext_vector_type(4), aligned(8)));      // four floats on an 8-byte boundary
 __device__ __forceinline__ float2 load_global_f2(const float2* p)
 {
 #if WR_GLOBAL_SAMPLE_LOADS && defined(__HIP_DEVICE_COMPILE__)
@@ -684,17 +680,10 @@ __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrie
             } else if (NB == 4) {
                 *reinterpret_cast<float4*>(lp) = make_float4(WR_WT(Y[j].re), WR_WT(WR_T16_2 - are), WR_WT(Y[j].im), WR_WT(WR_T16_2 - aim));
             } else {
-#if WR_QAM64_WIDE_STORES
-                // 24 bytes per carrier on an 8-byte boundary: one 16-byte and one 8-byte store instead of three of 8
-                *reinterpret_cast<wr_f4u*>(lp) = wr_f4u{ WR_WT(Y[j].re), WR_WT(WR_T64_4 - are),
-                                                         WR_WT(WR_T64_2 - __builtin_fabsf(are - WR_T64_4)), WR_WT(Y[j].im) };
-                reinterpret_cast<float2*>(lp)[2] = make_float2(WR_WT(WR_T64_4 - aim), WR_WT(WR_T64_2 - __builtin_fabsf(aim - WR_T64_4)));
-#else
                 float2* l2 = reinterpret_cast<float2*>(lp);
                 l2[0] = make_float2(WR_WT(Y[j].re), WR_WT(WR_T64_4 - are));
                 l2[1] = make_float2(WR_WT(WR_T64_2 - __builtin_fabsf(are - WR_T64_4)), WR_WT(Y[j].im));
                 l2[2] = make_float2(WR_WT(WR_T64_4 - aim), WR_WT(WR_T64_2 - __builtin_fabsf(aim - WR_T64_4)));
-#endif
             }
 #undef WR_WT
         }
