@@ -17,9 +17,13 @@
 #pragma once
 #include "wr_device.h"
 #include "wr_kernels.h"
+#include <type_traits>
 
 namespace wr {
 
+#ifndef WR_SPLIT_SYMBOL_LOOP
+#define WR_SPLIT_SYMBOL_LOOP 1
+#endif
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
@@ -926,15 +930,20 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 
     int pk = 0;                                                // (s - 2) mod 127: index into the pilot polarity sequence
     float t4 = WR_T4_64F[0];                                   // float32 (2 pi s 80) / 64 of the current symbol
-    for (int s = 0;; s++) {
-        const int off0 = fs + (s < 2 ? 64 * s : 128 + 80 * (s - 2) + 16);
+    // One symbol of the four frames.  DATA (compile time): the symbol is known to be a data symbol (s >= 3) -- the steady
+    // state of the loop, compiled without the tests and flag juggling of the LTS and SIGNAL symbols (the scalar side of an
+    // iteration costs almost what its vector side does: 32 more scalar instructions per symbol = +2 % time).  Returns false
+    // when no row has a symbol left.
+    auto symbol = [&](auto data_c, const int s) __attribute__((always_inline)) -> bool {
+        constexpr bool DATA = decltype(data_c)::value;
+        const int off0 = fs + ((!DATA && s < 2) ? 64 * s : 128 + 80 * (s - 2) + 16);
         bool act = alive && (s <= n_sym + 2);
-        if (act && (off0 + 64 > L || (s > 2 && (s - 3) >= (int)prm.max_sym))) {
+        if (act && (off0 + 64 > L || ((DATA || s > 2) && (s - 3) >= (int)prm.max_sym))) {
             flags |= WIFIRX_F_TRUNCATED;
             alive = false;
             act = false;
         }
-        if (!__any(act)) break;
+        if (!__any(act)) return false;
 
         // ---- samples r + 16 j of the symbol (rows without a symbol get zeros) ----
         c32 v[4], cur[4];
@@ -952,7 +961,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         }
         {   // one rotation by the total offset (spec rule 8): the lane's base phasor from the exact integer phase at
             // s = 0, 1, 9, 17, ..., in between carried from symbol to symbol by exp(j theta 80); then steps of exp(j theta 16)
-            if (s < 2 || ((s - 1) & 7) == 0) {                   // wave-uniform
+            if ((!DATA && s < 2) || ((s - 1) & 7) == 0) {        // wave-uniform
                 const unsigned long long ph = Qp * (unsigned long long)(unsigned)(off0 + r);
                 sp_sincos_q((uint32_t)(ph >> 32), (uint32_t)ph, wbase.im, wbase.re);
             } else {
@@ -1021,7 +1030,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         uint32_t sgn = 0;
         c32 S, cur0, cur1, cur2, cur3;
         float er = 0.0f;
-        if (s >= 2) {
+        if (DATA || s >= 2) {
             const uint64_t bits = pk < 64 ? (WR_POLARITY_NEG_LO >> pk) : (WR_POLARITY_NEG_HI >> (pk - 64));
             sgn = (uint32_t)(bits & 1ull) << 31;
             S = cflip(csub(cadd(cadd(X11, X39), X25), X53), sgn);
@@ -1055,12 +1064,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             for (int j = 0; j < 4; j++) X[j] = sp_rot(X[j], sn, cs);
         }
         // (5) IIR
-        if (s >= 2) d_er = fma_(0.1f, er, 0.9f * d_er);
+        if (DATA || s >= 2) d_er = fma_(0.1f, er, 0.9f * d_er);
         // (6a) COMB: this symbol's pilots (polarity removed) are the channel at bins 11, 25, 39, 53, their mean stands at
         //      the band edges (bins 0 and 64); linear interpolation, then d_H = 0.8 d_H + 0.2 H (d_H = H at s = 0)
         if (COMB) {
             c32 n1 = row_bcast<11>(X[0]), n2 = row_bcast<9>(X[1]), n3 = row_bcast<7>(X[2]), n4 = row_bcast<5>(X[3]);
-            if (s < 2) n2 = cneg(n2);
+            if (!DATA && s < 2) n2 = cneg(n2);
             else { n1 = cflip(n1, sgn); n2 = cflip(n2, sgn); n3 = cflip(n3, sgn); n4 = cflip(n4, sgn ^ 0x80000000u); }
             const c32 sum = cadd(cadd(cadd(n1, n2), n3), n4);
             const c32 n0 = { 0.25f * sum.re, 0.25f * sum.im };
@@ -1071,7 +1080,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 const bool lo = (r + 16 * j) <= edge[j];            // segment j (nodes j, j+1) or j+1 (nodes j+1, j+2)
                 const c32 a = lo ? node[j] : node[j + 1], b = lo ? node[j + 1] : node[j + 2];
                 const float hr = fma_(b.re, cw[j], a.re * cu[j]), hi = fma_(b.im, cw[j], a.im * cu[j]);
-                if (s == 0) DHl[64 * j] = make_float2(hr, hi);
+                if (!DATA && s == 0) DHl[64 * j] = make_float2(hr, hi);
                 else {
                     const float2 o = DHl[64 * j];
                     DHl[64 * j] = make_float2(0.8f * o.x + 0.2f * hr, 0.8f * o.y + 0.2f * hi);
@@ -1079,10 +1088,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             }
         }
         // (6) LS equalizer
-        if (s == 0) {
+        if (!DATA && s == 0) {
 #pragma unroll
             for (int j = 0; j < 4; j++) Hl[64 * j] = make_float2(X[j].re, X[j].im);
-        } else if (s == 1) {
+        } else if (!DATA && s == 1) {
             float nv[4], sv[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1118,7 +1127,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             c32 Y[4];
             int carrier[4];
             c32 HU[4];                                   // STA: this symbol's per-bin estimates of my bins
-            const bool const_mag = (LMS || STA) && __all(s == 2 || n_bpsc <= 2);      // wave-uniform
+            const bool const_mag = (LMS || STA) && __all((!DATA && s == 2) || n_bpsc <= 2);      // wave-uniform
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 carrier[j] = carrier0[j];
@@ -1136,7 +1145,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                         Y[j].re = fma_(X[j].im, g0.y, X[j].re * g0.x) * rd;
                         Y[j].im = fma_(X[j].im, g0.x, -(X[j].re * g0.y)) * rd;
                         if (LMS || STA) {
-                            const int nbl = (s == 2) ? 1 : n_bpsc;
+                            const int nbl = (!DATA && s == 2) ? 1 : n_bpsc;
                             const c32 pt = point_of(decide(Y[j], nbl), nbl);
                             // 1 / |point|^2: BPSK and QPSK points all have one magnitude, the quotient is formed once per wave
                             // (same value); the wave divides per bin only when a row carries 16- or 64-QAM
@@ -1184,7 +1193,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            if (s == 2) {
+            if (!DATA && s == 2) {
                 // (7) SIGNAL: per frame, gather the 48 BPSK decisions in carrier order, de-interleave, Viterbi
                 uint64_t bal[4];
 #pragma unroll
@@ -1277,6 +1286,17 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 if (act) n_out = q + 1;
             }
         }
+        return true;
+    };
+    {
+        int s = 0;
+        bool more = true;
+        for (; more && s < 3; s++) more = symbol(std::false_type{}, s);
+#if WR_SPLIT_SYMBOL_LOOP
+        for (; more; s++) more = symbol(std::true_type{}, s);
+#else
+        for (; more; s++) more = symbol(std::false_type{}, s);
+#endif
     }
     if (r == 0 && out >= 0) {
         wifirx_frame fr;
