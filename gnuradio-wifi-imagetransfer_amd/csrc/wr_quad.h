@@ -934,14 +934,21 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     // state of the loop, compiled without the tests and flag juggling of the LTS and SIGNAL symbols (the scalar side of an
     // iteration costs almost what its vector side does: 32 more scalar instructions per symbol = +2 % time).  Returns false
     // when no row has a symbol left.
+    int s_end = 0;          // data loop: first symbol index the row no longer has
+    int nbu_all = 0;        // data loop: the constellation all rows with data symbols share, 0 if they differ
     auto symbol = [&](auto data_c, const int s) __attribute__((always_inline)) -> bool {
         constexpr bool DATA = decltype(data_c)::value;
         const int off0 = fs + ((!DATA && s < 2) ? 64 * s : 128 + 80 * (s - 2) + 16);
-        bool act = alive && (s <= n_sym + 2);
-        if (act && (off0 + 64 > L || ((DATA || s > 2) && (s - 3) >= (int)prm.max_sym))) {
-            flags |= WIFIRX_F_TRUNCATED;
-            alive = false;
-            act = false;
+        bool act;
+        if (DATA) {
+            act = s < s_end;                    // how far the row's frame goes was settled when the data symbols began
+        } else {
+            act = alive && (s <= n_sym + 2);
+            if (act && (off0 + 64 > L || (s > 2 && (s - 3) >= (int)prm.max_sym))) {
+                flags |= WIFIRX_F_TRUNCATED;
+                alive = false;
+                act = false;
+            }
         }
         if (!__any(act)) return false;
 
@@ -1245,9 +1252,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 const bool has_idx = idx_all != nullptr, has_car = car_all != nullptr;
                 int out_l = out;                                  // the row's plane words are addressed from the record index
                 asm volatile("" : "+v"(out_l));                   // every symbol anew: no loop-invariant pointer in registers
-                const int nbu = __builtin_amdgcn_readfirstlane(n_bpsc);      // the loop ran: some lane is active, but
                 const uint64_t act_m = __ballot(act);
-                const bool uniform = (act_m & ~__ballot(n_bpsc == nbu)) == 0 && (act_m & 1ull);
+                // DATA: whether the rows with data symbols share a constellation was settled once (nbu_all > 0: they do)
+                const int nbu = DATA ? (nbu_all > 0 ? nbu_all : 1) : __builtin_amdgcn_readfirstlane(n_bpsc);      // the loop ran: some lane is active, but
+                const bool uniform = DATA ? nbu_all > 0 : (act_m & ~__ballot(n_bpsc == nbu)) == 0 && (act_m & 1ull);
                 const float w1[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
                 const bool csi = prm.llr_csi != 0 && llr_all != nullptr;     // wave-uniform
 #define WR_STORE(NB, OK)                                                                                        \
@@ -1293,6 +1301,18 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         bool more = true;
         for (; more && s < 3; s++) more = symbol(std::false_type{}, s);
 #if WR_SPLIT_SYMBOL_LOOP
+        if (more) {
+            // the data symbols of a row: 3 .. n_sym + 2, as far as the copied samples (off0 + 64 <= L) and the output rows
+            // (s - 3 < max_sym) go; a frame that is cut short is flagged here, once
+            const int s_fit = 2 + (L - fs - 208) / 80, s_max = (int)prm.max_sym + 2;
+            const int s_lim = s_fit < s_max ? s_fit : s_max;
+            const bool cut = alive && s_lim < n_sym + 2;
+            if (cut) { flags |= WIFIRX_F_TRUNCATED; alive = false; }
+            s_end = (alive || cut) ? (cut ? s_lim : n_sym + 2) + 1 : 0;
+            const uint64_t has_data = __ballot(s_end > 3);
+            const int nb_first = has_data ? __builtin_amdgcn_readlane(n_bpsc, (int)__builtin_ctzll(has_data)) : 0;
+            nbu_all = (has_data & ~__ballot(n_bpsc == nb_first)) == 0 ? nb_first : 0;
+        }
         for (; more; s++) more = symbol(std::true_type{}, s);
 #else
         for (; more; s++) more = symbol(std::false_type{}, s);
