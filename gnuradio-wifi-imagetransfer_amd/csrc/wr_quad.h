@@ -24,6 +24,9 @@ namespace wr {
 #ifndef WR_SPLIT_SYMBOL_LOOP
 #define WR_SPLIT_SYMBOL_LOOP 1
 #endif
+#ifndef WR_PLAIN_STORES
+#define WR_PLAIN_STORES 1
+#endif
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
@@ -658,12 +661,16 @@ __device__ __forceinline__ float row_xor_sum16(float v)
 // CSI: every LLR is multiplied by w[j] = |H|^2 of its sub-carrier (spec rule 12).
 // idx / car / llr: the rows of the wave's FIRST record (wave-uniform pointers: the stores take them from scalar
 // registers); row_o / row_l: this row's distance from there in decisions / in LLR values (32 bits per lane).
-template <int NB, bool CSI>
+// PLAIN: the caller has established (wave-uniform) that decisions and LLRs are wanted by every row with a symbol and the
+// equalised points by none -- the usual output set; the flags are then compile-time and the four bins leave without a
+// scalar branch per output and bin.
+template <int NB, bool CSI, bool PLAIN = false>
 __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrier)[4], bool ok, int q,
                                            uint8_t* __restrict__ idx, float2* __restrict__ car,
-                                           float* __restrict__ llr, bool has_idx, bool has_car, bool want_llr,
+                                           float* __restrict__ llr, bool has_idx_, bool has_car_, bool want_llr_,
                                            const float (&w)[4], uint32_t row_o, uint32_t row_l)
 {
+    const bool has_idx = PLAIN ? true : has_idx_, has_car = PLAIN ? false : has_car_, want_llr = PLAIN ? true : want_llr_;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (!(ok && carrier[j] >= 0)) continue;
@@ -936,6 +943,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     // when no row has a symbol left.
     int s_end = 0;          // data loop: first symbol index the row no longer has
     int nbu_all = 0;        // data loop: the constellation all rows with data symbols share, 0 if they differ
+    bool plain_all = false; // data loop: every row with data symbols wants decisions + LLRs, none the equalised points
     auto symbol = [&](auto data_c, const int s) __attribute__((always_inline)) -> bool {
         constexpr bool DATA = decltype(data_c)::value;
         const int off0 = fs + ((!DATA && s < 2) ? 64 * s : 128 + 80 * (s - 2) + 16);
@@ -1261,6 +1269,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #define WR_STORE(NB, OK)                                                                                        \
                 { if (csi) { const float wq[4] = { Wl[0], Wl[64], Wl[128], Wl[192] };                                   \
                              store_bins<NB, true>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq, row_o, row_l); }  \
+                  else if (DATA && plain_all) store_bins<NB, false, true>(Y, carrier, OK, q, idx, car, llr, true, false, true, w1, row_o, row_l); \
                   else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, w1, row_o, row_l); \
                   if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
                             store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
@@ -1312,6 +1321,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             const uint64_t has_data = __ballot(s_end > 3);
             const int nb_first = has_data ? __builtin_amdgcn_readlane(n_bpsc, (int)__builtin_ctzll(has_data)) : 0;
             nbu_all = (has_data & ~__ballot(n_bpsc == nb_first)) == 0 ? nb_first : 0;
+            // the usual output set: decisions + LLRs for every row with data symbols, no equalised points
+            plain_all = WR_PLAIN_STORES && idx_all != nullptr && car_all == nullptr && (has_data & ~__ballot(want_llr)) == 0;
         }
         for (; more; s++) more = symbol(std::true_type{}, s);
 #else
