@@ -27,6 +27,9 @@ namespace wr {
 #ifndef WR_PLAIN_STORES
 #define WR_PLAIN_STORES 1
 #endif
+#ifndef WR_CONST_DATA_MASK
+#define WR_CONST_DATA_MASK 1
+#endif
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
@@ -673,7 +676,14 @@ __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrie
     const bool has_idx = PLAIN ? true : has_idx_, has_car = PLAIN ? false : has_car_, want_llr = PLAIN ? true : want_llr_;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+#if WR_CONST_DATA_MASK
+        // which lanes hold a data sub-carrier in register j is a constant of the lane <-> bin map (bins r + 16 j): the
+        // execution mask comes from a scalar constant, not from a comparison of the carrier number
+        const uint64_t row_bits = j == 0 ? 0xF7C0ull : j == 1 ? 0xFDFFull : j == 2 ? 0xFF7Eull : 0x07DFull;      // (the loop is unrolled)
+        if (!(ok && __builtin_amdgcn_inverse_ballot_w64(row_bits * 0x0001000100010001ull))) continue;
+#else
         if (!(ok && carrier[j] >= 0)) continue;
+#endif
         const uint32_t oq = (uint32_t)(q * 48 + carrier[j]);
         const uint32_t o = row_o + oq;
         if (has_idx) idx[o] = decide(Y[j], NB);
