@@ -30,6 +30,9 @@ namespace wr {
 #ifndef WR_CONST_DATA_MASK
 #define WR_CONST_DATA_MASK 1
 #endif
+#ifndef WR_NB_LOOPS
+#define WR_NB_LOOPS 1
+#endif
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
@@ -954,8 +957,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     int s_end = 0;          // data loop: first symbol index the row no longer has
     int nbu_all = 0;        // data loop: the constellation all rows with data symbols share, 0 if they differ
     bool plain_all = false; // data loop: every row with data symbols wants decisions + LLRs, none the equalised points
-    auto symbol = [&](auto data_c, const int s) __attribute__((always_inline)) -> bool {
+    // NBC (compile time, data symbols only): > 0 = every row with data symbols carries this constellation AND the outputs are
+    // the usual set (decisions + LLRs without weights, no equalised points): the store code is picked at compile time; 0 = decided
+    // per symbol.
+    auto symbol = [&](auto data_c, auto nb_c, const int s) __attribute__((always_inline)) -> bool {
         constexpr bool DATA = decltype(data_c)::value;
+        constexpr int NBC = decltype(nb_c)::value;
         const int off0 = fs + ((!DATA && s < 2) ? 64 * s : 128 + 80 * (s - 2) + 16);
         bool act;
         if (DATA) {
@@ -1283,7 +1290,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                   else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, w1, row_o, row_l); \
                   if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
                             store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
-                if (uniform) {
+                if (NBC != 0) {
+                    store_bins<(NBC ? NBC : 1), false, true>(Y, carrier, act, q, idx, car, llr, true, false, true, w1, row_o, row_l);
+                    if (HB) { __builtin_amdgcn_sched_barrier(0);
+                              store_hbits<(NBC ? NBC : 1)>(Y, act, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); }
+                } else if (uniform) {
                     if (nbu == 1)      WR_STORE(1, act)
                     else if (nbu == 2) WR_STORE(2, act)
                     else if (nbu == 4) WR_STORE(4, act)
@@ -1318,7 +1329,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     {
         int s = 0;
         bool more = true;
-        for (; more && s < 3; s++) more = symbol(std::false_type{}, s);
+        typedef std::integral_constant<int, 0> nb_any;
+        for (; more && s < 3; s++) more = symbol(std::false_type{}, nb_any{}, s);
 #if WR_SPLIT_SYMBOL_LOOP
         if (more) {
             // the data symbols of a row: 3 .. n_sym + 2, as far as the copied samples (off0 + 64 <= L) and the output rows
@@ -1334,9 +1346,16 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             // the usual output set: decisions + LLRs for every row with data symbols, no equalised points
             plain_all = WR_PLAIN_STORES && idx_all != nullptr && car_all == nullptr && (has_data & ~__ballot(want_llr)) == 0;
         }
-        for (; more; s++) more = symbol(std::true_type{}, s);
+        const bool special = WR_NB_LOOPS && more && nbu_all > 0 && plain_all && !(prm.llr_csi != 0 && llr_all != nullptr);      // wave-uniform
+        if (special && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, s);
+        else if (special && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, s);
+#if WR_NB_LOOPS > 1
+        else if (special && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, s);
+        else if (special && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, s);
+#endif
+        else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, s);
 #else
-        for (; more; s++) more = symbol(std::false_type{}, s);
+        for (; more; s++) more = symbol(std::false_type{}, nb_any{}, s);
 #endif
     }
     if (r == 0 && out >= 0) {
