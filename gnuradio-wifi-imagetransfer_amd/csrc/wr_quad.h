@@ -33,6 +33,12 @@ namespace wr {
 #ifndef WR_NB_LOOPS
 #define WR_NB_LOOPS 1
 #endif
+#ifndef WR_POLARITY_WINDOW
+#define WR_POLARITY_WINDOW 1
+#endif
+#ifndef WR_T4_POINTER
+#define WR_T4_POINTER 1
+#endif
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
@@ -949,7 +955,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     float2*  car = car_all ? car_all + (size_t)out_base * per : nullptr;
 
     int pk = 0;                                                // (s - 2) mod 127: index into the pilot polarity sequence
+    uint64_t polw = WR_POLARITY_NEG_LO;                        // ... or: the sequence from the current symbol on,
+    int poln = 64;                                             //     the bits left in the window
+    bool polhi = false;                                        //     and which half of the 127 it came from
+    (void)pk;
     float t4 = WR_T4_64F[0];                                   // float32 (2 pi s 80) / 64 of the current symbol
+    const float* t4_next = WR_T4_64F + 1;                      // data loop: where the factor after next stands
     // One symbol of the four frames.  DATA (compile time): the symbol is known to be a data symbol (s >= 3) -- the steady
     // state of the loop, compiled without the tests and flag juggling of the LTS and SIGNAL symbols (the scalar side of an
     // iteration costs almost what its vector side does: 32 more scalar instructions per symbol = +2 % time).  Returns false
@@ -1044,7 +1055,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             // upstream: 2 pi s 80 (eps0 + d_er) / 64 in double; spec: the factor that depends on s alone comes from a
             // float32 table, eps0 and d_er are float32
             const float kf = t4 * (eps0 + d_er);
+#if WR_T4_POINTER
+            if (DATA) { t4 = *t4_next; t4_next++; }             // the next symbol's factor (s + 1 <= 514: inside the table), requested a whole iteration early
+            else { t4 = WR_T4_64F[s + 1]; t4_next = WR_T4_64F + (s + 2); }
+#else
             t4 = WR_T4_64F[s < 518 ? s + 1 : 519];              // the next symbol's factor: requested a whole iteration early
+#endif
             // b = phasor of bin r + 16; lane 0 of the row holds exp(-j kf 16), whose conjugate is the step
             c32 b;
             sp_sincos_small(kf * (float)(r - 16), b.im, b.re);
@@ -1063,8 +1079,15 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         c32 S, cur0, cur1, cur2, cur3;
         float er = 0.0f;
         if (DATA || s >= 2) {
+#if WR_POLARITY_WINDOW
+            // the polarity sequence as a window that moves one bit per symbol (two scalar shifts; refilled every 64 / 63 symbols)
+            sgn = (uint32_t)polw << 31;
+            polw >>= 1;
+            if (--poln == 0) { polhi = !polhi; polw = polhi ? WR_POLARITY_NEG_HI : WR_POLARITY_NEG_LO; poln = polhi ? 63 : 64; }
+#else
             const uint64_t bits = pk < 64 ? (WR_POLARITY_NEG_LO >> pk) : (WR_POLARITY_NEG_HI >> (pk - 64));
             sgn = (uint32_t)(bits & 1ull) << 31;
+#endif
             S = cflip(csub(cadd(cadd(X11, X39), X25), X53), sgn);
             cur0 = cflip(X11, sgn);
             cur1 = cflip(X25, sgn);
@@ -1075,7 +1098,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             c32 acc = cadd(cadd(cadd(sp_conj_mul(prev0, cur0), sp_conj_mul(prev1, cur1)),
                                 sp_conj_mul(prev2, cur2)), sp_conj_mul(prev3, cur3));
             er = sp_atan2(acc.im, acc.re) * er_scale;
+#if !WR_POLARITY_WINDOW
             pk = pk == 126 ? 0 : pk + 1;                       // (s - 2) mod 127 of the next symbol
+#endif
         } else {
             S = cadd(cadd(csub(X11, X25), X39), X53);
             cur0 = X11; cur1 = cneg(X25); cur2 = X39; cur3 = X53;
