@@ -31,7 +31,7 @@ namespace wr {
 #define WR_CONST_DATA_MASK 1
 #endif
 #ifndef WR_NB_LOOPS
-#define WR_NB_LOOPS 1
+#define WR_NB_LOOPS 1       // 1: BPSK and QPSK only (measured: loops of their own for 16- and 64-QAM bring nothing), 2: all four constellations
 #endif
 #ifndef WR_POLARITY_WINDOW
 #define WR_POLARITY_WINDOW 1
