@@ -1304,8 +1304,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 asm volatile("" : "+v"(out_l));                   // every symbol anew: no loop-invariant pointer in registers
                 const uint64_t act_m = __ballot(act);
                 // DATA: whether the rows with data symbols share a constellation was settled once (nbu_all > 0: they do)
-                const int nbu = DATA ? (nbu_all > 0 ? nbu_all : 1) : __builtin_amdgcn_readfirstlane(n_bpsc);      // the loop ran: some lane is active, but
-                const bool uniform = DATA ? nbu_all > 0 : (act_m & ~__ballot(n_bpsc == nbu)) == 0 && (act_m & 1ull);
+                // ... if not (rows of different rates and lengths), the rows that are left may still agree: the first active row's
+                // constellation against the others', symbol by symbol
+                const bool settled = DATA && nbu_all > 0;                    // wave-uniform
+                const int nbu = settled ? nbu_all : __builtin_amdgcn_readlane(n_bpsc, act_m ? (int)__builtin_ctzll(act_m) : 0);
+                const bool uniform = settled || (act_m & ~__ballot(n_bpsc == nbu)) == 0;
                 const float w1[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
                 const bool csi = prm.llr_csi != 0 && llr_all != nullptr;     // wave-uniform
 #define WR_STORE(NB, OK)                                                                                        \
