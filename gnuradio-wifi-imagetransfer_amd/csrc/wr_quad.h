@@ -40,7 +40,7 @@ namespace wr {
 #define WR_T4_POINTER 1
 #endif
 #ifndef WR_STORE_AS_LINES
-#define WR_STORE_AS_LINES 1
+#define WR_STORE_AS_LINES 2       // 1: in the kernels without plane output only, 2: in both
 #endif
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
@@ -1363,7 +1363,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                   if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
                             store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
                 if (NBC != 0) {
-                    if (WR_STORE_AS_LINES && !HB && lines_ok)
+                    if (WR_STORE_AS_LINES && (!HB || WR_STORE_AS_LINES > 1) && lines_ok)
                         store_bins_lines<(NBC == 2 ? 2 : 1)>(Y, carrier, act, q, idx, llr, row_o, row_l, qlds, row, r);
                     else
                     store_bins<(NBC ? NBC : 1), false, true>(Y, carrier, act, q, idx, car, llr, true, false, true, w1, row_o, row_l);
