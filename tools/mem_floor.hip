@@ -211,10 +211,13 @@ int main(int argc, char** argv)
         res[c] = best;
     }
     // one JSON line for profiles/*_mem_floor.json (bench.py quotes combined_ms)
+    // (combined_ms: the rows' LLRs and decisions as whole 16-byte pieces -- what the kernel's BPSK / QPSK loops do since the end
+    // of round 3; combined_old_shape_ms: one float2 + one byte per bin, as before and as 16- / 64-QAM rows still leave)
     printf("{\"tool\": \"tools/mem_floor.hip\", \"n_slots\": %u, \"combined_ms\": %.3f, \"symbols_only_ms\": %.3f, "
+           "\"combined_old_shape_ms\": %.3f, \"symbols_only_old_shape_ms\": %.3f, "
            "\"loads_only_ms\": %.3f, \"stores_only_ms\": %.3f, \"what\": \"the global loads and stores of demod_batch_kernel on "
            "config 2 (same addresses, order and wave organisation), no arithmetic\"}\n",
-           n_slots, res[0], res[1], res[2], res[3]);
+           n_slots, res[4], res[5], res[0], res[1], res[2], res[3]);
     for (int depth = 1; depth <= 2; depth++) {
         float best = 1e9f;
         for (int it = 0; it < 5; it++) {
