@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         // ---- samples r + 16 j of the symbol (rows without a symbol get zeros) ----
         c32 v[4], cur[4];
         {
-            if (lo_zero) {              // act => off0 + 63 < L <= m_hi: every sample of the symbol is in range
+            if (NBC != 0 || lo_zero) {  // act => off0 + 63 < L <= m_hi: every sample of the symbol is in range (the constellation loops are entered only then)
                 // rows without a symbol read the first 64 samples of their (or the wave's first) frame instead: finite
                 // numbers that no output sees -- cheaper than zeroing eight registers per symbol for them
                 const float2* p = xb + ((act ? off0 : 0) + r);
@@ -1232,7 +1232,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 carrier[j] = carrier0[j];
-                asm volatile("" : "+v"(carrier[j]));     // keeps base + carrier out of loop-invariant registers
+                if (NBC == 0) asm volatile("" : "+v"(carrier[j]));     // keeps base + carrier out of loop-invariant registers (the constellation loops do better without)
                 Y[j] = { 0.0f, 0.0f };
                 HU[j] = X[j];
                 // every bin is equalised, data or not (LS: G = 0 on unused bins; the others: H = 1 there from the LTS step on;
@@ -1363,7 +1363,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                   if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
                             store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
                 if (NBC != 0) {
-                    if (WR_STORE_AS_LINES && (!HB || WR_STORE_AS_LINES > 1) && lines_ok)
+                    if (WR_STORE_AS_LINES && (NBC == 1 || NBC == 2) && (!HB || WR_STORE_AS_LINES > 1) && lines_ok)
                         store_bins_lines<(NBC == 2 ? 2 : 1)>(Y, carrier, act, q, idx, llr, row_o, row_l, qlds, row, r);
                     else
                     store_bins<(NBC ? NBC : 1), false, true>(Y, carrier, act, q, idx, car, llr, true, false, true, w1, row_o, row_l);
@@ -1381,7 +1381,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                     WR_STORE(6, act && n_bpsc == 6)
                 }
 #undef WR_STORE
-                if (stat_all != nullptr) {
+                if (NBC == 0 && stat_all != nullptr) {     // (the constellation loops are entered only without it)
                     // moments of the equalised points for the probe_mpsk_snr_est consumer (IRS_AP.py:275,312): per lane
                     // the data bins r + 16 j in ascending j (others 0), the row by the spec's xor tree, the frame symbol
                     // after symbol
@@ -1421,7 +1421,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             // the usual output set: decisions + LLRs for every row with data symbols, no equalised points
             plain_all = WR_PLAIN_STORES && idx_all != nullptr && car_all == nullptr && (has_data & ~__ballot(want_llr)) == 0;
         }
-        const bool special = WR_NB_LOOPS && more && nbu_all > 0 && plain_all && !(prm.llr_csi != 0 && llr_all != nullptr);      // wave-uniform
+        const bool special = WR_NB_LOOPS && more && nbu_all > 0 && plain_all && !(prm.llr_csi != 0 && llr_all != nullptr) &&
+                             lo_zero && stat_all == nullptr;      // wave-uniform
         if (special && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, s);
         else if (special && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, s);
 #if WR_NB_LOOPS > 1
