@@ -31,7 +31,7 @@ namespace wr {
 #define WR_CONST_DATA_MASK 1
 #endif
 #ifndef WR_NB_LOOPS
-#define WR_NB_LOOPS 1       // 1: BPSK and QPSK only (measured: loops of their own for 16- and 64-QAM bring nothing), 2: all four constellations
+#define WR_NB_LOOPS 2       // 1: BPSK and QPSK only, 2: all four constellations (loops of their own for 16- and 64-QAM bring nothing by themselves; they carry the whole-line stores)
 #endif
 #ifndef WR_POLARITY_WINDOW
 #define WR_POLARITY_WINDOW 1
@@ -40,20 +40,28 @@ namespace wr {
 #define WR_T4_POINTER 1
 #endif
 #ifndef WR_STORE_AS_LINES
-#define WR_STORE_AS_LINES 2       // 1: in the kernels without plane output only, 2: in both
+#define WR_STORE_AS_LINES 3       // 1: BPSK / QPSK rows in the kernels without plane output only, 2: in both, 3: 16- / 64-QAM rows as well (needs WR_NB_LOOPS 2)
 #endif
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
-#define WR_QLDS_SCRATCH 768
-#define WR_QLDS_H       (WR_QLDS_SCRATCH)            // 4 x 64 float2: channel estimate, lane-private slots
-#define WR_QLDS_TW      (WR_QLDS_H + 512)              // 6 x 16 float2: stage-1/2 twiddles by row lane
-#define WR_QLDS_PREV    (WR_QLDS_TW + 192)             // 4 rows x 4 float2: pilots of the previous symbol
-#define WR_QLDS_W       (WR_QLDS_PREV + 32)            // 4 x 64 floats: |H|^2 of the LS estimate (LLR weight, lane-private slots)
-#define WR_QLDS_STAT    (WR_QLDS_W + 256)            // 4 rows x 4 floats: running sums of |y|, |y|^2, |y|^4 (sym_stats output)
-#define WR_QLDS_FLOATS  (WR_QLDS_STAT + 16)          // per wave; the preamble phase uses the first 1536 floats for two frames' samples
-#define WR_QLDS_DH      (WR_QLDS_FLOATS)             // COMB only: 4 x 64 float2, the running estimate d_H
-#define WR_QLDS_FLOATS_EQ(EQ) (WR_QLDS_FLOATS + ((EQ) == WIFIRX_EQ_COMB ? 512 : 0))
+// LDS of the symbol loop, per wave (floats).  The scratch area at the front serves the FFT transposes (512 floats), the SIGNAL
+// decoder's survivor words, STA's window exchange and the staging of a symbol's output rows (store_bins_lines: 432 floats
+// for BPSK / QPSK rows, 1200 for 64-QAM = 4 x 1152 B of LLRs + 4 x 48 decisions).  The COMB instance keeps the short scratch
+// area (its running estimate d_H takes another 2 kB; with the long one sixteen waves would no longer fit a CU's 160 kB) and
+// with it the per-bin stores for 16- / 64-QAM rows.
+#ifndef WR_QLDS_LONG
+#define WR_QLDS_LONG 1200
+#endif
+#define WR_QLDS_SCRATCH_EQ(EQ) ((EQ) == WIFIRX_EQ_COMB ? 768 : WR_QLDS_LONG)
+#define WR_QLDS_H(S)       (S)                        // 4 x 64 float2: channel estimate, lane-private slots
+#define WR_QLDS_TW(S)      (WR_QLDS_H(S) + 512)       // 6 x 16 float2: stage-1/2 twiddles by row lane
+#define WR_QLDS_PREV(S)    (WR_QLDS_TW(S) + 192)      // 4 rows x 4 float2: pilots of the previous symbol
+#define WR_QLDS_W(S)       (WR_QLDS_PREV(S) + 32)     // 4 x 64 floats: |H|^2 of the LS estimate (LLR weight, lane-private slots)
+#define WR_QLDS_STAT(S)    (WR_QLDS_W(S) + 256)       // 4 rows x 4 floats: running sums of |y|, |y|^2, |y|^4 (sym_stats output)
+#define WR_QLDS_FLOATS(S)  (WR_QLDS_STAT(S) + 16)     // per wave; the preamble phase uses the first 1536 floats for two frames' samples
+#define WR_QLDS_DH(S)      (WR_QLDS_FLOATS(S))        // COMB only: 4 x 64 float2, the running estimate d_H
+#define WR_QLDS_FLOATS_EQ(EQ) (WR_QLDS_FLOATS(WR_QLDS_SCRATCH_EQ(EQ)) + ((EQ) == WIFIRX_EQ_COMB ? 512 : 0))
 
 // a sample through the global-memory path: the symbol loop's sample pointer is rebuilt from lane exchanges, which hides
 // its address space from the compiler (it would take the flat path, which also counts on the LDS counter)
@@ -723,41 +731,64 @@ __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrie
     }
 }
 
-// The same stores for BPSK / QPSK as whole 16-byte pieces: a row's LLRs of one symbol are 192 / 384 contiguous bytes and
-// its decisions 48, but lane r holds bins r + 16 j, so store_bins() writes them as four pieces per row that start and end
-// inside 128-byte lines (and the decisions as single bytes).  Here every lane drops its values into the FFT's LDS area (free
-// at this point of the symbol) in carrier order and the row's lanes write the row back out as 16-byte pieces (decisions: one
-// dword for lanes 0..11): three store instructions per symbol instead of eight, every line written whole.  The memory probe
-// (tools/mem_floor.hip) runs 11 % faster in this shape; the kernel gained nothing from it while instruction issue kept it
-// 0.7 ms above that probe, and does since the data loop was slimmed down.  Same values, same addresses.
+// The same stores as whole 16-byte pieces: a row's LLRs of one symbol are 192 NB contiguous bytes (192 / 384 / 768 / 1152)
+// and its decisions 48, but lane r holds bins r + 16 j, so store_bins() writes them as four pieces per row that start and end
+// inside 128-byte lines -- for 64-QAM as three 8-byte stores per bin with the lanes 24 bytes apart -- and the decisions as
+// single bytes.  Here every lane drops its values into the scratch LDS area (free at this point of the symbol) in carrier
+// order and the row's lanes write the row back out as 16-byte pieces (decisions: one dword for lanes 0..11): 2 / 3 / 4 / 6
+// store instructions per symbol instead of 8 / 8 / 8 / 16, every line written whole.  The memory probes run 11 % (QPSK,
+// tools/mem_floor.hip) and 15 % (64-QAM, tools/mem_floor64.hip: 5.71 -> 4.83 ms on the config-3 geometry) faster in this
+// shape; the kernel follows since the data loop was slimmed down: -3 % on config 2, -13 % on the config-3 geometry, -5 % on
+// long 16-QAM frames.  Same values, same addresses.
 // Requires (caller, wave-uniform): decisions and LLRs wanted by every active row, no weights, idx 4-byte and llr 16-byte aligned.
 template <int NB>
 __device__ __forceinline__ void store_bins_lines(const c32 (&Y)[4], const int (&carrier)[4], bool ok, int q,
                                                  uint8_t* __restrict__ idx, float* __restrict__ llr,
                                                  uint32_t row_o, uint32_t row_l, float* stage, int row, int r)
 {
-    static_assert(NB == 1 || NB == 2, "BPSK and QPSK only");
-    char* srow = reinterpret_cast<char*>(stage) + row * (192 * NB);
-    uint8_t* irow = reinterpret_cast<uint8_t*>(stage) + 1536 + row * 48;
+    static_assert(NB == 1 || NB == 2 || NB == 4 || NB == 6, "constellation");
+    // 16- / 64-QAM rows (768 / 1152 bytes of LLRs per symbol: 48 / 72 pieces) need the long scratch area (WR_QLDS_SCRATCH_EQ)
+    constexpr int ROWB = 192 * NB, IDX0 = NB <= 2 ? 1536 : 4 * ROWB;
+    char* srow = reinterpret_cast<char*>(stage) + row * ROWB;
+    uint8_t* irow = reinterpret_cast<uint8_t*>(stage) + IDX0 + row * 48;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint64_t row_bits = j == 0 ? 0xF7C0ull : j == 1 ? 0xFDFFull : j == 2 ? 0xFF7Eull : 0x07DFull;      // (the loop is unrolled)
         if (!__builtin_amdgcn_inverse_ballot_w64(row_bits * 0x0001000100010001ull)) continue;
-        if (NB == 1) *reinterpret_cast<float*>(srow + 4 * carrier[j]) = Y[j].re;
-        else         *reinterpret_cast<float2*>(srow + 8 * carrier[j]) = make_float2(Y[j].re, Y[j].im);
+        const float are = __builtin_fabsf(Y[j].re), aim = __builtin_fabsf(Y[j].im);
+        if (NB == 1)      *reinterpret_cast<float*>(srow + 4 * carrier[j]) = Y[j].re;
+        else if (NB == 2) *reinterpret_cast<float2*>(srow + 8 * carrier[j]) = make_float2(Y[j].re, Y[j].im);
+        else if (NB == 4) *reinterpret_cast<float4*>(srow + 16 * carrier[j]) = make_float4(Y[j].re, WR_T16_2 - are, Y[j].im, WR_T16_2 - aim);
+        else {
+            float2* l2 = reinterpret_cast<float2*>(srow + 24 * carrier[j]);
+            l2[0] = make_float2(Y[j].re, WR_T64_4 - are);
+            l2[1] = make_float2(WR_T64_2 - __builtin_fabsf(are - WR_T64_4), Y[j].im);
+            l2[2] = make_float2(WR_T64_4 - aim, WR_T64_2 - __builtin_fabsf(aim - WR_T64_4));
+        }
         irow[carrier[j]] = decide(Y[j], NB);
     }
     __builtin_amdgcn_wave_barrier();
-    const float4 a = *reinterpret_cast<const float4*>(srow + 16 * r);
-    float4 b = a;
-    if (NB == 2) b = *reinterpret_cast<const float4*>(srow + 256 + 16 * (r & 7));
+    // piece r + 16 k of the row, k = 0 .. (12 NB - 1) / 16 (the last k for the lanes that still have one)
+    constexpr int NK = (12 * NB + 15) / 16, TAIL = 12 * NB - 16 * (NK - 1);       // BPSK 1 / 12, QPSK 2 / 8, 16-QAM 3 / 16, 64-QAM 5 / 8
+    // (separate variables, not an array: an array indexed in a loop under a lane condition stays in scratch memory)
+#define WR_PIECE(k) (*reinterpret_cast<const float4*>(srow + 256 * (k) + 16 * (((k) == NK - 1 && TAIL == 8) ? (r & 7) : r)))     // (BPSK: lanes 12..15 read into the next row's area, and store nothing)
+    const float4 p0 = WR_PIECE(0);
+    float4 p1 = p0, p2 = p0, p3 = p0, p4 = p0;
+    if (NK > 1) p1 = WR_PIECE(1);
+    if (NK > 2) p2 = WR_PIECE(2);
+    if (NK > 3) p3 = WR_PIECE(3);
+    if (NK > 4) p4 = WR_PIECE(4);
+#undef WR_PIECE
     const uint32_t d = reinterpret_cast<const uint32_t*>(irow)[r < 12 ? r : 0];
     __builtin_amdgcn_wave_barrier();
     if (ok) {
         char* lp = reinterpret_cast<char*>(llr) + (uint32_t)((row_l + (uint32_t)(q * 48 * NB)) * 4u + 16u * r);
-        if (NB == 2 || r < 12) *reinterpret_cast<float4*>(lp) = a;
-        if (NB == 2 && r < 8) *reinterpret_cast<float4*>(lp + 256) = b;
+        if (NK > 1 || r < TAIL)            *reinterpret_cast<float4*>(lp) = p0;
+        if (NK > 2 || (NK == 2 && r < TAIL)) *reinterpret_cast<float4*>(lp + 256) = p1;
+        if (NK > 3 || (NK == 3 && r < TAIL)) *reinterpret_cast<float4*>(lp + 512) = p2;
+        if (NK > 4 || (NK == 4 && r < TAIL)) *reinterpret_cast<float4*>(lp + 768) = p3;
+        if (NK == 5 && r < TAIL)             *reinterpret_cast<float4*>(lp + 1024) = p4;
         if (r < 12) *reinterpret_cast<uint32_t*>(idx + (row_o + (uint32_t)(q * 48) + 4u * r)) = d;
     }
 }
@@ -881,6 +912,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     float4* __restrict__ stat_all = dout.sym_stats;
     uint32_t* __restrict__ hb_all = dout.hbits;
     constexpr bool LMS = EQ == WIFIRX_EQ_LMS, COMB = EQ == WIFIRX_EQ_COMB, STA = EQ == WIFIRX_EQ_STA;
+    constexpr int QS = WR_QLDS_SCRATCH_EQ(EQ);      // where the per-wave state behind the scratch area begins
     constexpr bool DIV = EQ != WIFIRX_EQ_LS;         // Y = X / H by division (LS multiplies by G = conj(H)/|H|^2)
     const int row = lane >> 4, r = lane & 15;
     // ---- row-uniform frame state, one copy per lane ----
@@ -939,7 +971,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 
     // ---- twiddles of stage 1 (output q = j at n = r) and stage 2 (lane (q1 = r>>2, m = r&3)): a 6 x 16 table in
     //      LDS, read back every symbol (registers are the scarce resource of this kernel, the LDS pipe is idle) ----
-    float2* twl = reinterpret_cast<float2*>(qlds + WR_QLDS_TW);
+    float2* twl = reinterpret_cast<float2*>(qlds + WR_QLDS_TW(QS));
     if (row == 0) {
 #pragma unroll
         for (int j = 1; j < 4; j++) {
@@ -948,12 +980,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             twl[(j + 2) * 16 + r] = make_float2(WR_TWIDDLE64[2 * e2], WR_TWIDDLE64[2 * e2 + 1]);
         }
     }
-    float* stl = qlds + WR_QLDS_STAT + 4 * row;                           // the row's running sums (lane r = 0 updates them)
+    float* stl = qlds + WR_QLDS_STAT(QS) + 4 * row;                           // the row's running sums (lane r = 0 updates them)
     if (stat_all != nullptr && r < 4) stl[r] = 0.0f;
-    float2* Hl = reinterpret_cast<float2*>(qlds + WR_QLDS_H) + lane;      // element j at Hl[64 j]
-    float2* pvl = reinterpret_cast<float2*>(qlds + WR_QLDS_PREV) + 4 * row;
-    float* Wl = qlds + WR_QLDS_W + lane;                                  // element j at Wl[64 j]
-    float2* DHl = reinterpret_cast<float2*>(qlds + (COMB ? WR_QLDS_DH : WR_QLDS_H)) + lane;   // COMB: d_H; else = Hl
+    float2* Hl = reinterpret_cast<float2*>(qlds + WR_QLDS_H(QS)) + lane;      // element j at Hl[64 j]
+    float2* pvl = reinterpret_cast<float2*>(qlds + WR_QLDS_PREV(QS)) + 4 * row;
+    float* Wl = qlds + WR_QLDS_W(QS) + lane;                                  // element j at Wl[64 j]
+    float2* DHl = reinterpret_cast<float2*>(qlds + (COMB ? WR_QLDS_DH(QS) : WR_QLDS_H(QS))) + lane;   // COMB: d_H; else = Hl
     float cw[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, cu[4] = { 0.0f, 0.0f, 0.0f, 0.0f };           // COMB: interpolation weights
     if (COMB) {
 #pragma unroll
@@ -1363,8 +1395,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                   if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
                             store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
                 if (NBC != 0) {
-                    if (WR_STORE_AS_LINES && (NBC == 1 || NBC == 2) && (!HB || WR_STORE_AS_LINES > 1) && lines_ok)
-                        store_bins_lines<(NBC == 2 ? 2 : 1)>(Y, carrier, act, q, idx, llr, row_o, row_l, qlds, row, r);
+                    if (WR_STORE_AS_LINES && (NBC <= 2 || (WR_STORE_AS_LINES > 2 && !COMB)) && (!HB || WR_STORE_AS_LINES > 1) && lines_ok)
+                        store_bins_lines<(NBC ? NBC : 1)>(Y, carrier, act, q, idx, llr, row_o, row_l, qlds, row, r);
                     else
                     store_bins<(NBC ? NBC : 1), false, true>(Y, carrier, act, q, idx, car, llr, true, false, true, w1, row_o, row_l);
                     if (HB) { __builtin_amdgcn_sched_barrier(0);
@@ -1425,9 +1457,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                              lo_zero && stat_all == nullptr;      // wave-uniform
         if (special && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, s);
         else if (special && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, s);
-#if WR_NB_LOOPS > 1
-        else if (special && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, s);
-        else if (special && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, s);
+#if WR_NB_LOOPS > 1     // (not in the COMB instance: its scratch area is too short for these rows' line stores, and the loops alone cost it 6 %)
+        else if (!COMB && special && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, s);
+        else if (!COMB && special && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, s);
 #endif
         else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, s);
 #else
