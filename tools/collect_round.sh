@@ -27,6 +27,7 @@ if [ "$PART" = 2 ]; then
   ./tools/mfma_f32_probe.bin > $OUT/mfma_f32_probe.txt 2>&1
   ./tools/mfma_valu_coexec.bin > $OUT/mfma_valu_coexec.txt 2>&1
   ./tools/valu_rate.bin > $OUT/valu_rate.txt 2>&1
+  [ -x tools/mem_floor64.bin ] && ./tools/mem_floor64.bin > $OUT/mem_floor64.txt 2>&1
   if [ -f ab/preamble_only.so ]; then
     WIFIRX_LIB=$ROOT/ab/preamble_only.so python bench.py --steps 5 --warmup 2 --no-cpu --pdu-steps 0 > $OUT/preamble_only.json 2>/dev/null
     python3 -c "import json; j=json.load(open('$OUT/preamble_only.json')); print('preamble only ms', j['roofline']['kernel_ms'])"

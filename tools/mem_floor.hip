@@ -48,6 +48,22 @@ __global__ __launch_bounds__(256, 4) void pattern(const float2* __restrict__ x, 
         }
         if (s >= 3) {
             const int q = s - 3;
+            if (do_stores == 3) {      // as 2, but the decisions of eight symbols leave together: 384 bytes per row = 24 pieces of 16 B
+                const uint32_t slot0 = slot - row;
+                for (int c = lane; c < 96; c += 64) {
+                    const int rw = c / 24, k = c % 24;
+                    float4* dst = reinterpret_cast<float4*>(llr + ((size_t)(slot0 + rw) * n_sym + q) * 48) + k;
+                    *dst = make_float4(v[0].x + v[2].y, v[1].y + v[3].x, v[2].x + v[0].y, v[3].y + v[1].x);
+                }
+                if ((q & 7) == 7 || q == n_sym - 1) {
+                    const int n16 = 3 * ((q & 7) + 1);
+                    float4* dst = reinterpret_cast<float4*>(ip + (q & ~7) * 48);
+                    const float4 w = make_float4(v[0].x, v[1].x, v[2].y, v[3].y);
+                    if (r < n16) dst[r] = w;
+                    if (16 + r < n16) dst[16 + r] = w;
+                }
+                continue;
+            }
             if (do_stores == 2) {      // whole lines: 96 chunks of 16 B of LLRs per wave and symbol, 12 dwords of decisions per row
                 const uint32_t slot0 = slot - row;
                 for (int c = lane; c < 96; c += 64) {
@@ -183,11 +199,11 @@ int main(int argc, char** argv)
     (void)hipMemset(x, 0x3c, (size_t)n_slots * slot_len * sizeof(float2));
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    const char* names[6] = { "loads+stores+preamble", "loads+stores", "loads only", "stores only",
-                             "loads+line stores+preamble", "loads+line stores" };
-    const int cfg[6][3] = { { 1, 1, 1 }, { 0, 1, 1 }, { 0, 1, 0 }, { 0, 0, 1 }, { 1, 1, 2 }, { 0, 1, 2 } };
-    float res[6];
-    for (int c = 0; c < 6; c++) {
+    const char* names[8] = { "loads+stores+preamble", "loads+stores", "loads only", "stores only",
+                             "loads+line stores+preamble", "loads+line stores", "loads+line stores, idx x8+preamble", "loads+line stores, idx x8" };
+    const int cfg[8][3] = { { 1, 1, 1 }, { 0, 1, 1 }, { 0, 1, 0 }, { 0, 0, 1 }, { 1, 1, 2 }, { 0, 1, 2 }, { 1, 1, 3 }, { 0, 1, 3 } };
+    float res[8];
+    for (int c = 0; c < 8; c++) {
         float best = 1e9f;
         for (int it = 0; it < 5; it++) {
             (void)hipEventRecord(e0, 0);
@@ -198,6 +214,8 @@ int main(int argc, char** argv)
             case 2: hipLaunchKernelGGL((pattern<0, 1, 0>), g, b, 0, 0, x, n_slots, slot_len, n_sym, idx, llr, o); break;
             case 3: hipLaunchKernelGGL((pattern<0, 0, 1>), g, b, 0, 0, x, n_slots, slot_len, n_sym, idx, llr, o); break;
             case 4: hipLaunchKernelGGL((pattern<1, 1, 2>), g, b, 0, 0, x, n_slots, slot_len, n_sym, idx, llr, o); break;
+            case 6: hipLaunchKernelGGL((pattern<1, 1, 3>), g, b, 0, 0, x, n_slots, slot_len, n_sym, idx, llr, o); break;
+            case 7: hipLaunchKernelGGL((pattern<0, 1, 3>), g, b, 0, 0, x, n_slots, slot_len, n_sym, idx, llr, o); break;
             default: hipLaunchKernelGGL((pattern<0, 1, 2>), g, b, 0, 0, x, n_slots, slot_len, n_sym, idx, llr, o); break;
             }
             (void)hipEventRecord(e1, 0);
@@ -211,13 +229,14 @@ int main(int argc, char** argv)
         res[c] = best;
     }
     // one JSON line for profiles/*_mem_floor.json (bench.py quotes combined_ms)
+    // (combined_idx_x8_ms: an experiment -- the decisions of eight symbols written together; the kernel did not follow, profiles/r03_ab_idx8.txt)
     // (combined_ms: the rows' LLRs and decisions as whole 16-byte pieces -- what the kernel's BPSK / QPSK loops do since the end
     // of round 3; combined_old_shape_ms: one float2 + one byte per bin, as before and as 16- / 64-QAM rows still leave)
     printf("{\"tool\": \"tools/mem_floor.hip\", \"n_slots\": %u, \"combined_ms\": %.3f, \"symbols_only_ms\": %.3f, "
            "\"combined_old_shape_ms\": %.3f, \"symbols_only_old_shape_ms\": %.3f, "
-           "\"loads_only_ms\": %.3f, \"stores_only_ms\": %.3f, \"what\": \"the global loads and stores of demod_batch_kernel on "
+           "\"loads_only_ms\": %.3f, \"stores_only_ms\": %.3f, \"combined_idx_x8_ms\": %.3f, \"what\": \"the global loads and stores of demod_batch_kernel on "
            "config 2 (same addresses, order and wave organisation), no arithmetic\"}\n",
-           n_slots, res[4], res[5], res[0], res[1], res[2], res[3]);
+           n_slots, res[4], res[5], res[0], res[1], res[2], res[3], res[6]);
     for (int depth = 1; depth <= 2; depth++) {
         float best = 1e9f;
         for (int it = 0; it < 5; it++) {
