@@ -48,15 +48,18 @@ def make_batch(n, slot_len, seed, max_len=1200, snrs=SNRS):
     return iq.reshape(-1)
 
 
-def run(n=20000, seed=1, long_frames=False, snrs=SNRS, equalisers=(0, 1, 2, 3), decode_small_max=None):
+def run(n=20000, seed=1, long_frames=False, snrs=SNRS, equalisers=(0, 1, 2, 3), decode_small_max=None, plain=False):
     """One campaign; returns the result dictionary (`all_bit_exact` is the verdict).  decode_small_max: forces decode_mac's
-    kernel choice (0: the throughput decoder with 128 frames per wave for every batch; None: the library's default)."""
+    kernel choice (0: the throughput decoder with 128 frames per wave for every batch; None: the library's default).
+    plain: the output set bench.py times -- decisions + LLRs, no equalised points, no CSI: waves whose frames share a rate
+    (the generator's groups of 8..63) then run the kernel's constellation loops with whole-line stores."""
     slot_len, max_sym, llr_bits = (45056, 511, 1) if long_frames else (8192, 96, 6)
     from oracle import oracle as orc
     t0 = time.perf_counter()
     iq = make_batch(n, slot_len, seed, 1531 if long_frames else 1200, snrs)
     res = {"frames": n, "slot_len": slot_len, "seed": seed, "snrs_db": list(snrs), "generate_s": time.perf_counter() - t0,
-           "decode_small_max": decode_small_max, "equalisers": {}}
+           "decode_small_max": decode_small_max, "outputs": "decisions + LLRs" if plain else "decisions + LLRs + equalised points + CSI",
+           "equalisers": {}}
     threads = os.cpu_count() or 1
     old_env = os.environ.get("WIFIRX_DECODE_SMALL_MAX")
     if decode_small_max is not None:
@@ -64,8 +67,8 @@ def run(n=20000, seed=1, long_frames=False, snrs=SNRS, equalisers=(0, 1, 2, 3), 
     try:
         for ce in equalisers:
             name = ("LS", "LMS", "COMB", "STA")[ce]
-            rx = capi.WifiRx(max_sym=max_sym, llr_bits=llr_bits, want_carrier=True, chan_est=ce)
-            r = rx.demod_batch(iq, slot_len, want_csi=True)
+            rx = capi.WifiRx(max_sym=max_sym, llr_bits=llr_bits, want_carrier=not plain, chan_est=ce)
+            r = rx.demod_batch(iq, slot_len, want_csi=not plain)
             d = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=2048)
             rx.close()
             prm = orc.make_params(max_sym=max_sym, llr_bits=llr_bits, chan_est=ce)
@@ -76,8 +79,8 @@ def run(n=20000, seed=1, long_frames=False, snrs=SNRS, equalisers=(0, 1, 2, 3), 
                 "frame_records": int((r["frames"] != o["frames"]).sum()),
                 "decisions": int((r["idx"] != o["idx"]).sum()),
                 "llr_values": int((r["llr"].view(np.uint32) != o["llr"].view(np.uint32)).sum()),
-                "equalised_points": int((r["carrier"].view(np.uint64) != o["eq"].view(np.uint64)).sum()),
-                "csi_values": int((r["csi"].view(np.uint64) != o["csi"].view(np.uint64)).sum()),
+                "equalised_points": 0 if plain else int((r["carrier"].view(np.uint64) != o["eq"].view(np.uint64)).sum()),
+                "csi_values": 0 if plain else int((r["csi"].view(np.uint64) != o["csi"].view(np.uint64)).sum()),
                 "flags_after_decode": int((d["frames"]["flags"] != of["flags"]).sum()),
             }
             dec = (d["frames"]["flags"] & capi.F_DECODED) != 0

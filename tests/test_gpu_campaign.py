@@ -43,6 +43,18 @@ def test_random_frames_four_equalisers(tag, seed, snrs):
     assert res["equalisers"]["LS"]["crc_ok"] > (0.5 if min(snrs) >= 6 else 0.1) * res["frames"]
 
 
+def test_random_frames_plain_outputs():
+    """The output set bench.py times (decisions + LLRs alone): the generator's frames come in groups of one rate, so most
+    waves run the kernel's constellation loops with whole-line stores -- with random lead-ins, lengths, SNRs and channels,
+    and ragged waves where two groups meet."""
+    import parity_campaign as pc
+    res = pc.run(20000, 308, plain=True)
+    _record("frames_seed308_plain_outputs", res)
+    for name, v in res["equalisers"].items():
+        assert v["total_mismatches"] == 0, (name, v["mismatches"])
+        assert v["detected"] > 0.5 * res["frames"]
+
+
 def test_random_frames_throughput_decoder():
     """The same kind of batch with decode_mac forced onto the throughput kernel (128 frames per wave, lane = two frames):
     mixed-rate waves, every wave position filled."""
