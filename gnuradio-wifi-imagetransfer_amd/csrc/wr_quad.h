@@ -42,6 +42,9 @@ namespace wr {
 #ifndef WR_STORE_AS_LINES
 #define WR_STORE_AS_LINES 3       // 1: BPSK / QPSK rows in the kernels without plane output only, 2: in both, 3: 16- / 64-QAM rows as well (needs WR_NB_LOOPS 2)
 #endif
+#ifndef WR_FLAT_STAGING
+#define WR_FLAT_STAGING 1        // store_bins_lines: the four bins of a lane staged without per-bin execution masks (BPSK .. 16-QAM)
+#endif
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
@@ -752,6 +755,26 @@ __device__ __forceinline__ void store_bins_lines(const c32 (&Y)[4], const int (&
     char* srow = reinterpret_cast<char*>(stage) + row * ROWB;
     uint8_t* irow = reinterpret_cast<uint8_t*>(stage) + IDX0 + row * 48;
     __builtin_amdgcn_wave_barrier();
+#if WR_FLAT_STAGING
+    if (NB <= 4) {
+        // one straight piece of code for the four bins of a lane: EVERY lane writes, the lanes whose bin carries no data (pilots,
+        // DC, guards: a constant of the lane <-> bin map) into a dump area behind the rows.  The four per-bin regions under an
+        // execution mask of their own cost three scalar instructions and a branch each, and kept every compare -> select pair
+        // of the decisions back to back (two idle issue slots per pair).  (64-QAM: the scratch area has no room for a dump.)
+        constexpr int ESZ = 4 * NB, DUMP_L = IDX0 + 192, DUMP_I = DUMP_L + 64 * ESZ;
+        const int lane = 16 * row + r;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool data = carrier[j] >= 0;
+            char* lw = data ? srow + ESZ * carrier[j] : reinterpret_cast<char*>(stage) + DUMP_L + ESZ * lane;
+            uint8_t* iw = data ? irow + carrier[j] : reinterpret_cast<uint8_t*>(stage) + DUMP_I + lane;
+            if (NB == 1)      *reinterpret_cast<float*>(lw) = Y[j].re;
+            else if (NB == 2) *reinterpret_cast<float2*>(lw) = make_float2(Y[j].re, Y[j].im);
+            else              *reinterpret_cast<float4*>(lw) = make_float4(Y[j].re, WR_T16_2 - __builtin_fabsf(Y[j].re), Y[j].im, WR_T16_2 - __builtin_fabsf(Y[j].im));
+            *iw = decide(Y[j], NB);
+        }
+    } else
+#endif
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint64_t row_bits = j == 0 ? 0xF7C0ull : j == 1 ? 0xFDFFull : j == 2 ? 0xFF7Eull : 0x07DFull;      // (the loop is unrolled)

@@ -3,10 +3,11 @@
 in rate, length, SNR, CFO, lead-in and channel (flat / multipath), for every equaliser.  The pytest parity cases
 are hand-picked and small; this is the bulk check behind them.  Prints one JSON line.
 
-    python tests/campaigns/parity_campaign.py [n_frames=20000] [seed=1] [long]
+    python tests/campaigns/parity_campaign.py [n_frames=20000] [seed=1] [long | plain]
 
 `long`: slots of 45056 samples, PSDUs up to 1530 bytes at every rate (up to 511 OFDM symbols: the longest frames
 decode_mac accepts, and the renormalisation of its 16-bit path metrics over 12 000+ trellis steps).
+`plain`: the output set bench.py times (decisions + LLRs alone): the kernel's constellation loops with whole-line stores.
 """
 import json
 import os
@@ -109,7 +110,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     long_frames = len(sys.argv) > 3 and sys.argv[3] == "long"
-    print(json.dumps(run(n, seed, long_frames)))
+    plain = len(sys.argv) > 3 and sys.argv[3] == "plain"
+    print(json.dumps(run(n, seed, long_frames, plain=plain)))
 
 
 if __name__ == "__main__":

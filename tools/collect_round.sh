@@ -41,6 +41,7 @@ if [ "$PART" = 3 ]; then
   python tests/campaigns/lts_rule6.py 1400 5 0 0.56 > $OUT/lts_rule6_thr56.json 2> $OUT/c1.err; python3 -c "import json; print(json.load(open('$OUT/lts_rule6_thr56.json'))['totals'])"
   python tests/campaigns/lts_rule6.py 1400 6 0 0.35 > $OUT/lts_rule6_thr35.json 2> $OUT/c2.err; python3 -c "import json; print(json.load(open('$OUT/lts_rule6_thr35.json'))['totals'])"
   python tests/campaigns/parity_campaign.py 60000 31 > $OUT/parity_campaign_seed31.json 2> $OUT/c3.err; tail -c 200 $OUT/parity_campaign_seed31.json; echo
+  python tests/campaigns/parity_campaign.py 100000 93 plain > $OUT/parity_campaign_seed93_plain_outputs.json 2> $OUT/c4.err; tail -c 200 $OUT/parity_campaign_seed93_plain_outputs.json; echo
   python tests/campaigns/stream_campaign.py 400 40 2 > $OUT/stream_campaign.json 2> $OUT/c5.err; tail -c 300 $OUT/stream_campaign.json; echo
   python tests/campaigns/ber_sweep.py 100000 0 > $OUT/config3_ber_sweep.json 2> $OUT/c6.err; tail -c 300 $OUT/config3_ber_sweep.json; echo
 fi
