@@ -1283,7 +1283,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             c32 Y[4];
             int carrier[4];
             c32 HU[4];                                   // STA: this symbol's per-bin estimates of my bins
-            const bool const_mag = (LMS || STA) && __all((!DATA && s == 2) || n_bpsc <= 2);      // wave-uniform
+            // (in a constellation loop the rows' constellation is the compile-time NBC: decisions and points of LMS / STA are then
+            //  compiled for it, without the per-lane walk through all four)
+            const bool const_mag = (LMS || STA) && (NBC != 0 ? NBC <= 2 : __all((!DATA && s == 2) || n_bpsc <= 2));      // wave-uniform
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 carrier[j] = carrier0[j];
@@ -1291,9 +1293,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 Y[j] = { 0.0f, 0.0f };
                 HU[j] = X[j];
                 // every bin is equalised, data or not (LS: G = 0 on unused bins; the others: H = 1 there from the LTS step on;
-                // pilot and unused bins are never stored, and no branch has to fence them off -- except in the STA instance,
-                // whose register allocation is the better for it: 20.1 vs 21.1 ms)
-                if (!STA || carrier[j] >= 0) {
+                // pilot and unused bins are never stored, and no branch has to fence them off -- except in the STA instance's
+                // general loop, whose register allocation was the better for it: 20.1 vs 21.1 ms; in its constellation loops the
+                // fence costs 1.4 %)
+                if (!(STA && NBC == 0) || carrier[j] >= 0) {
                     const float2 g0 = DHl[64 * j];
                     if (DIV) {
                         // spec rule 11: one reciprocal of |H|^2 per bin, then products
@@ -1301,7 +1304,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                         Y[j].re = fma_(X[j].im, g0.y, X[j].re * g0.x) * rd;
                         Y[j].im = fma_(X[j].im, g0.x, -(X[j].re * g0.y)) * rd;
                         if (LMS || STA) {
-                            const int nbl = (!DATA && s == 2) ? 1 : n_bpsc;
+                            const int nbl = NBC != 0 ? NBC : (!DATA && s == 2) ? 1 : n_bpsc;
                             const c32 pt = point_of(decide(Y[j], nbl), nbl);
                             // 1 / |point|^2: BPSK and QPSK points all have one magnitude, the quotient is formed once per wave
                             // (same value); the wave divides per bin only when a row carries 16- or 64-QAM
