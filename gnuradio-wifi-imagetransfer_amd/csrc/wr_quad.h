@@ -1313,7 +1313,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                             else           rp = sp_recip(fma_(pt.im, pt.im, pt.re * pt.re));
                             const float tr = fma_(X[j].im, pt.im, X[j].re * pt.re) * rp;
                             const float ti = fma_(X[j].im, pt.re, -(X[j].re * pt.im)) * rp;
-                            if (LMS && act) Hl[64 * j] = make_float2(0.5f * g0.x + 0.5f * tr, 0.5f * g0.y + 0.5f * ti);
+                            // (no test of `act`: a row without a symbol has none left either, and what it writes into its own estimate is never read)
+                            if (LMS) Hl[64 * j] = make_float2(0.5f * g0.x + 0.5f * tr, 0.5f * g0.y + 0.5f * ti);
                             HU[j] = { tr, ti };
                         }
                     } else {
