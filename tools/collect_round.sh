@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box, through gpurun): tools/collect_round.sh <part> <tag>     part = 1 | 2 | 3
 # Runs the measurements the round's profiles/ are made from and leaves them under gpurun_out/collect_<tag>/.
+# Before the first call in a fresh container: tools/build_probes.sh (the probes and the preamble-only library are built here, not on the GPU box).
+# Do not edit csrc/ while a call is queued: gpurun snapshots the tree when the box is there, and the files are stamped with the hash of what it finds.
 # Part 1: bench, rocprofv3 kernel stats, PMC passes, memory floor.   Part 2: other geometries, host path, probes,
 # preamble-only build.   Part 3: parity / stream campaigns and the config-3 sweep.
 PART=$1; TAG=$2
