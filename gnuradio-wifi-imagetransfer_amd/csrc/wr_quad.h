@@ -1414,8 +1414,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 const bool uniform = settled || (act_m & ~__ballot(n_bpsc == nbu)) == 0;
                 const float w1[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
                 const bool csi = prm.llr_csi != 0 && llr_all != nullptr;     // wave-uniform
+                // (a caller that wants PDUs only asks for the bit planes alone: then the per-bin stores have nothing to write)
+                const bool no_bins = HB && !has_idx && !has_car && llr_all == nullptr;     // wave-uniform, constant for the launch
 #define WR_STORE(NB, OK)                                                                                        \
-                { if (csi) { const float wq[4] = { Wl[0], Wl[64], Wl[128], Wl[192] };                                   \
+                { if (no_bins) { }                                                                                      \
+                  else if (csi) { const float wq[4] = { Wl[0], Wl[64], Wl[128], Wl[192] };                                   \
                              store_bins<NB, true>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, wq, row_o, row_l); }  \
                   else if (DATA && plain_all) store_bins<NB, false, true>(Y, carrier, OK, q, idx, car, llr, true, false, true, w1, row_o, row_l); \
                   else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, w1, row_o, row_l); \
