@@ -169,10 +169,16 @@ class wifi_phy_rx(grshim.sync_block):
                     if n_out[i] > 0:
                         self.snr_probe.update_frame(st[i][0], st[i][1], st[i][2], 48 * n_out[i])
             if want_car and r["carrier"] is not None:
-                car = r["carrier"]
-                for i in range(nf):
-                    for sy in range(n_out[i]):
-                        pub(self._p_car, make({}, car[i, sy]))
+                car, p_car = r["carrier"], self._p_car
+                if not grshim.HAVE_GNURADIO:
+                    # on the shim a PDU is (dict, row view): rows by iteration over the frame's block (no index arithmetic per symbol)
+                    for i in range(nf):
+                        for row in car[i, :n_out[i]]:
+                            pub(p_car, ({}, row))
+                else:
+                    for i in range(nf):
+                        for sy in range(n_out[i]):
+                            pub(p_car, make({}, car[i, sy]))
             ok = [i for i in range(nf) if flags[i] & capi.F_CRC_OK]
             self.frames_ok += len(ok)
             self.frames_dropped += nf - len(ok)
