@@ -21,7 +21,15 @@ Rank 0 prints ONE JSON line (see the round prompt for the contract) with the ext
 "roofline" (dominant kernel: algorithmic bytes / HIP-event kernel time vs the 8 TB/s HBM peak, and the
 same on the bytes the PMC counters saw move), "cpu_baseline" (the oracle, timed on this host's cores on
 a bounded sample of the same batch), "host_path" (the drop-in block's work() fed with 8192-item host
-chunks), "samples_to_pdu" (demod + decode_mac) and "variants" (config 2 with CFO = 0).
+chunks), "samples_to_pdu" (demod + decode_mac), "ber_vs_tx" (hard decisions against the transmitted interleaved bits)
+and "variants": config 2 with CFO = 0, the config-3 and config-1 geometries, the reference's own output set (`carrier`
+on, IRS_AP.py:293) and the LMS / COMB / STA equalisers -- each with its kernel time, roofline fraction, channel BER and
+the parity of its first 4096 frames with the oracle.
+
+"roofline.box" is the same-run, same-process yardstick of THIS box (tools/box_probe.hip, libboxprobe.so -- measurement
+tooling, not product): a float4 stream at the kernel's read : write mix and the kernel's own loads and stores without
+arithmetic (combined, loads only, stores only), measured on the very buffers of the timed batch right after the parity
+checks.  `frac_of_mem_floor` and `kernel_vs_box_floor` come from these figures only, never from a profiles/ file.
 """
 from __future__ import annotations
 
@@ -72,6 +80,8 @@ def parse_args(argv=None):
                     help="frame ranges the PDU all-gather is cut into (N > 1); 0 = as many as keep every range on decode_mac's "
                          "fastest kernel (>= 600 000 frames per range: one range for 1 M frames)")
     ap.add_argument("--host-samples", type=int, default=96_000_000, help="samples pushed through work() in the host_path leg")
+    ap.add_argument("--no-variants", action="store_true", help="skip the other geometries / output sets / equalisers")
+    ap.add_argument("--variant-frames", type=int, default=0, help="frames per variant batch (0 = as --frames)")
     return ap.parse_args(argv)
 
 
@@ -113,6 +123,151 @@ def latest_profile(suffix):
         return None
 
 
+def device_clocks():
+    """rocm-smi's view of the device clocks, read BEFORE this process touches the GPU (a child process; nothing here
+    initialises HIP).  None when the tool is missing or refuses."""
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, timeout=20, text=True)
+        j = json.loads(r.stdout)
+        card = j.get("card0") or next(iter(j.values()))
+        return {k: v for k, v in card.items() if "clock" in k.lower()}
+    except Exception:
+        return None
+
+
+_BOXPROBE = None
+
+
+def boxprobe_lib():
+    """tools/libboxprobe.so (built by __graft_entry__.build()); None when absent.  The library carries the hash of the
+    source it was built from: a binary that does not match tools/box_probe.hip is reported as stale and not used."""
+    global _BOXPROBE
+    if _BOXPROBE is None:
+        import ctypes as C
+        import hashlib
+        path = os.path.join(ROOT, "tools", "libboxprobe.so")
+        try:
+            lib = C.CDLL(path)
+            lib.boxprobe_src_sha.restype = C.c_char_p
+            lib.boxprobe_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+            with open(os.path.join(ROOT, "tools", "box_probe.hip"), "rb") as f:
+                want = hashlib.sha256(f.read()).hexdigest()[:16]
+            have = lib.boxprobe_src_sha().decode()
+            _BOXPROBE = (lib, have, have == want)
+        except OSError:
+            _BOXPROBE = (None, None, False)
+    return _BOXPROBE
+
+
+def box_yardstick(iq_ptr, idx_ptr, llr_ptr, car_ptr, n_frames, slot_len, lead, n_sym, n_bpsc, reps=3):
+    """This box, this process, these buffers: the float4 stream and the demod kernel's own memory pattern (see the module
+    docstring).  Overwrites the idx / LLR / carrier rows -- call after the parity checks."""
+    import ctypes as C
+    lib, sha, fresh = boxprobe_lib()
+    if lib is None or not fresh:
+        return {"available": False, "probe_src_sha": sha, "stale": lib is not None}
+    out = (C.c_double * 8)()
+    rc = lib.boxprobe_run(iq_ptr, idx_ptr, llr_ptr, car_ptr, n_frames, slot_len, lead, n_sym, n_bpsc, reps, out)
+    if rc != 0:
+        return {"available": False, "probe_src_sha": sha, "hip_error": rc}
+    return {"available": True, "probe_src_sha": sha, "tool": "tools/box_probe.hip",
+            "stream_tbps": out[1] / (out[0] * 1e-3) / 1e12, "stream_ms": out[0], "stream_gb": out[1] / 1e9,
+            "mem_floor_ms": out[2], "symbols_only_ms": out[3], "loads_only_ms": out[4], "stores_only_ms": out[5],
+            "pattern_gb": out[6] / 1e9,
+            "note": "same run, same process, the timed batch's own buffers: float4 stream at the kernel's read:write mix; "
+                    "the demod kernel's global loads and stores without arithmetic (mem_floor = preamble reads + symbol "
+                    "loads + whole-line stores; loads / stores alone), best of %d launches each" % reps}
+
+
+def ber_vs_tx(torch, idx_t, frames_np, tx, n_bpsc, capi):
+    """Coded-bit BER of the hard decisions against the transmitted interleaved bits ("vs transmitted
+    bits"): slot k carries template k mod n_templates (wr_synth.hip); frames that did not demodulate completely at the
+    transmitted rate and length are counted apart (they have no decisions to compare)."""
+    n_t, n_sym = tx.data_idx.shape[0], tx.data_idx.shape[1]
+    n = (idx_t.shape[0] // n_t) * n_t
+    good = ((frames_np["flags"][:n] & capi.F_COMPLETE) != 0) & (frames_np["encoding"][:n] == tx.encoding) & \
+           (frames_np["n_sym"][:n] == n_sym)
+    ref = torch.from_numpy(np.ascontiguousarray(tx.data_idx.reshape(n_t, n_sym * 48))).to(idx_t.device)
+    d = idx_t[:n].view(n // n_t, n_t, n_sym * 48) ^ ref[None]
+    err = torch.zeros((n // n_t, n_t), dtype=torch.int32, device=idx_t.device)
+    for b in range(n_bpsc):
+        err += ((d >> b) & 1).sum(dim=2, dtype=torch.int32)
+    g = torch.from_numpy(good.reshape(n // n_t, n_t)).to(idx_t.device)
+    bit_errors = int((err * g).sum(dtype=torch.int64).item())
+    n_good = int(good.sum())
+    bits = n_good * n_sym * 48 * n_bpsc
+    return {"coded_ber": bit_errors / bits if bits else None, "bit_errors": bit_errors, "bits_compared": bits,
+            "frames_compared": n_good, "frames_not_demodulated": int(n - n_good),
+            "what": "hard decisions (wifirx_out.idx) vs the transmitter's interleaved coded bits, before decode_mac"}
+
+
+def run_variant(torch, capi, txgen, orc, name, enc, slot_len, n_frames, device, chan_est=0, want_carrier=False,
+                taps=None, snr_db=SNR_DB, cfo_max=CFO_MAX, n_templates=256, seed=4321, cores=1, yardstick=True,
+                parity_frames=4096, cite=""):
+    """One more geometry / output set / equaliser through the same timed kernel: device-resident batch made like the
+    headline's (host templates -> Philox AWGN + CFO on the device), kernel time by HIP events (mean of 3 after a warm-up),
+    roofline fraction on SURVEY.md 8(d)'s bytes (carrier rows included when on), channel BER, parity of the first frames
+    with the oracle, and -- for a geometry or output set of its own -- this box's memory yardstick."""
+    n_sym = txgen.n_sym_for(PSDU_LEN, enc)
+    n_bpsc = txgen.RATE_TABLE[enc][0]
+    tx = txgen.encode_psdus(txgen.make_psdus(n_templates, PSDU_LEN, seed=seed), enc)
+    samples = tx.samples
+    if taps is not None:         # multipath on the host templates (tests/golden/sv_taps.npy: one draw per template)
+        samples = txgen.impair(tx.samples, None, cfo=0.0, lead=0, total=tx.samples.shape[1] + taps.shape[1], taps=taps[:n_templates])
+    assert LEAD + samples.shape[1] <= slot_len
+    rx = capi.WifiRx(bandwidth=BANDWIDTH, frequency=FREQUENCY, sensitivity=0.56, chan_est=chan_est, max_sym=n_sym,
+                     llr_bits=n_bpsc, want_carrier=want_carrier, device=device)
+    iq = torch.empty((n_frames, slot_len, 2), dtype=torch.float32, device="cuda")
+    rx.synth_slots(samples, iq.data_ptr(), slot_len, n_frames, LEAD, snr_db, float(cfo_max), seed)
+    frames_t = torch.zeros((n_frames, 32), dtype=torch.uint8, device="cuda")
+    idx_t = torch.zeros((n_frames, n_sym * 48), dtype=torch.uint8, device="cuda")
+    llr_t = torch.zeros((n_frames, n_sym * 48 * n_bpsc), dtype=torch.float32, device="cuda")
+    car_t = torch.zeros((n_frames, n_sym * 48, 2), dtype=torch.float32, device="cuda") if want_carrier else None
+    torch.cuda.synchronize()
+    out = capi.Out(frames_t.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), car_t.data_ptr() if want_carrier else None,
+                   None, 0, 1, None)
+    ms = capi.C.c_float(0)
+
+    def demod(iters):
+        rx._check(capi.lib().wifirx_time_demod(rx._h, iq.data_ptr(), slot_len, n_frames, capi.C.byref(out), iters, capi.C.byref(ms)))
+        return ms.value
+
+    demod(1)
+    runs = [demod(1) for _ in range(3)]
+    kernel_ms = float(np.mean(runs))
+    fr = frames_t.cpu().numpy().view(capi.FRAME_DTYPE).reshape(-1)
+    bpf = algorithmic_bytes_per_frame(slot_len, n_sym, n_bpsc) + (384 * n_sym if want_carrier else 0)
+    res = {"what": name, "cite": cite, "frames": n_frames, "slot_len": slot_len, "encoding": enc, "n_sym": n_sym,
+           "chan_est": ["LS", "LMS", "COMB", "STA"][chan_est], "carrier": bool(want_carrier), "snr_db": snr_db,
+           "kernel_ms": kernel_ms, "kernel_ms_min": float(min(runs)),
+           "gsamples_per_s": float(n_frames) * slot_len / (kernel_ms * 1e-3) / 1e9,
+           "algorithmic_bytes_per_frame": bpf, "frac": bpf * n_frames / (kernel_ms * 1e-3) / HBM_PEAK,
+           "frames_complete": int(((fr["flags"] & capi.F_COMPLETE) != 0).sum())}
+    res["ber_vs_tx"] = ber_vs_tx(torch, idx_t.view(n_frames, n_sym * 48), fr, tx, n_bpsc, capi)
+    if orc is not None and parity_frames > 0:
+        n_p = min(parity_frames, n_frames)
+        prm = orc.make_params(bandwidth=BANDWIDTH, frequency=FREQUENCY, max_sym=n_sym, llr_bits=n_bpsc, chan_est=chan_est)
+        x = iq[:n_p].cpu().numpy().view(np.complex64).reshape(-1)
+        o = orc.demod_batch(x, slot_len, prm, want_eq=want_carrier, n_threads=cores)
+        mism = int((idx_t[:n_p].cpu().numpy().reshape(n_p, n_sym, 48) != o["idx"]).sum()) + \
+               int((llr_t[:n_p].cpu().numpy() != o["llr"]).sum()) + int((fr[:n_p] != o["frames"]).sum())
+        if want_carrier:
+            mism += int((car_t[:n_p].cpu().numpy().view(np.complex64).reshape(n_p, n_sym, 48) != o["eq"]).sum())
+        res["parity"] = {"frames_checked": n_p, "mismatching_values": mism}
+    if yardstick:
+        box = box_yardstick(iq.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), car_t.data_ptr() if want_carrier else None,
+                            n_frames, slot_len, LEAD, n_sym, n_bpsc)
+        res["box"] = box
+        if box.get("available"):
+            res["kernel_vs_box_floor"] = kernel_ms / box["mem_floor_ms"]
+    rx.close()
+    del iq, frames_t, idx_t, llr_t, car_t
+    torch.cuda.empty_cache()
+    return res
+
+
+
 def collective_info(dist, torch, backend, rank, local_rank, world, coll_dev):
     """What a reader of the JSON line needs to check that the collective library really saw N ranks: the backend as
     torch.distributed reports it, the RCCL version (torch.cuda.nccl.version(): RCCL on ROCm), the rank count as a
@@ -147,6 +302,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    clocks = device_clocks() if rank == 0 and not stub else None       # before anything here touches the GPU
     if world != args.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
@@ -386,10 +542,6 @@ def main():
         traffic_stale = bool(tj) and tj.get("csrc_sha") != sha_now
         moved_per_frame = tj["hbm_bytes_per_frame"] if tj else None
         traffic = moved_per_frame * n_frames / 1e9 if tj else None
-        floor = latest_profile("_mem_floor.json")
-        floor_stale = bool(floor) and floor.get("csrc_sha") != sha_now
-        if floor_stale:
-            floor = None
         achieved = bpf * n_frames / (kernel_ms_avg * 1e-3)
         moved = moved_per_frame * n_frames / (kernel_ms_avg * 1e-3) if tj and not traffic_stale else None
         result = {
@@ -435,7 +587,6 @@ def main():
                 "traffic_stale": traffic_stale,       # true: the PMC file was measured on other kernel sources than this tree's
                 "csrc_sha": sha_now,
                 "hw_floor_ms": (moved_per_frame * n_frames / HBM_ACHIEVABLE * 1e3) if tj and not traffic_stale else None,
-                "mem_floor_stale": floor_stale,
                 "kernel": "wr::demod_batch_kernel",
                 "kernel_ms": kernel_ms_avg,
                 "algorithmic_bytes_per_frame": bpf,
@@ -444,9 +595,8 @@ def main():
                 "hbm_achievable": HBM_ACHIEVABLE / 1e9,
                 "frac_of_achievable": achieved / HBM_ACHIEVABLE,
                 "bytes_moved_frac_of_achievable": moved / HBM_ACHIEVABLE if moved else None,
-                "mem_floor_ms": floor.get("combined_ms") if floor else None,
-                "mem_floor_source": floor["_file"] if floor else None,
-                "frac_of_mem_floor": (floor["combined_ms"] / kernel_ms_avg) if floor and floor.get("combined_ms") else None,
+                "box": None,                     # filled below: this box's own yardstick, same run, same process
+                "device_clocks_before_run": clocks,
             },
         }
         if pdu_leg is not None:
@@ -553,6 +703,22 @@ def main():
                                            "Python PDU per data symbol on `carrier`, as IRS_AP.py:293 wires it; never `value`"}
             blk.close()
 
+    # ---- channel BER of the timed batch and this box's own memory yardstick, on the timed buffers ----
+    if rank == 0:
+        result["ber_vs_tx"] = ber_vs_tx(torch, idx_t, fr, tx, n_bpsc, capi)
+        rx.sync()
+        torch.cuda.synchronize()
+        box = box_yardstick(iq.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), None, n_frames, SLOT_LEN, LEAD, n_sym, n_bpsc)
+        rf = result["roofline"]
+        rf["box"] = box
+        if box.get("available"):
+            rf["mem_floor_ms"] = box["mem_floor_ms"]
+            rf["mem_floor_source"] = "roofline.box (same run)"
+            rf["frac_of_mem_floor"] = box["mem_floor_ms"] / kernel_ms_avg
+            rf["kernel_vs_box_floor"] = kernel_ms_avg / box["mem_floor_ms"]
+            rf["kernel_vs_stream"] = kernel_ms_avg / (box["pattern_gb"] / box["stream_tbps"])      # ms the float4 stream needs for the pattern's bytes
+
+    if rank == 0 and world == 1 and not args.no_cpu:
         # ---- config 2, CFO = 0 variant: same frames and noise law, no carrier offset ----
         rx.synth_slots(tx.samples, iq.data_ptr(), SLOT_LEN, n_frames, LEAD, SNR_DB, 0.0, synth_seed, cfo.data_ptr())
         step()
@@ -563,6 +729,27 @@ def main():
                                        "frac": bpf * n_frames / (ms0 * 1e-3) / HBM_PEAK,
                                        "frames_complete": int(((fr0["flags"] & capi.F_COMPLETE) != 0).sum()),
                                        "note": "config 2 with CFO = 0 (IRS_tranceiver.py:121 range centre), device kernel time"}}
+        if not args.no_variants:
+            # the other BASELINE.json geometries, the reference's own output set and the other equalisers through the same
+            # kernel, each with channel BER and oracle parity of its first 4096 frames; the headline's buffers go first
+            del iq, idx_t, llr_t, hbits_t, psdu_t, out, out_hb
+            torch.cuda.empty_cache()
+            n_var = args.variant_frames or n_frames
+            taps = np.load(os.path.join(ROOT, "tests", "golden", "sv_taps.npy"))
+            V = result["variants"]
+            kw = dict(n_frames=n_var, device=local_rank, cores=cores)
+            V["config3_geometry"] = run_variant(torch, capi, txgen, orc, "BASELINE.json configs[2] geometry: 64-QAM 3/4, slot 1472, "
+                                                "multipath taps tests/golden/sv_taps.npy (utils/SV_channel.py:81-86,128 draws), "
+                                                "LS, 20 dB", 7, 1472, taps=taps, cite="gnu_radio/IRS_AP.py:81,268-285", **kw)
+            V["config1_geometry"] = run_variant(torch, capi, txgen, orc, "BASELINE.json configs[0] geometry: BPSK 1/2, slot 8576, "
+                                                "AWGN 20 dB", 0, 8576, cite="gnu_radio/IRS_AP.py:268-285", **kw)
+            V["carrier_on"] = run_variant(torch, capi, txgen, orc, "config 2 with the reference's own output set: equalised points "
+                                          "on `carrier` (want_carrier = 1), LS", ENCODING, SLOT_LEN, want_carrier=True,
+                                          cite="gnu_radio/IRS_AP.py:293,312-313", **kw)
+            for ce, nm in ((1, "lms"), (2, "comb"), (3, "sta")):
+                V[nm] = run_variant(torch, capi, txgen, orc, "config 2 with the %s equaliser" % nm.upper(), ENCODING, SLOT_LEN,
+                                    chan_est=ce, yardstick=False, cite="gnu_radio/IRS_AP.py:139-141", **kw)
+                V[nm]["vs_LS_same_run"] = V[nm]["kernel_ms"] / kernel_ms_avg
 
     if rank == 0:
         print(json.dumps(result))

@@ -87,6 +87,9 @@ struct wifirx_handle {
     void*  s_stats = nullptr;
     void*  s_hbits = nullptr;
     int    test_fail_alloc = 0, test_alloc_count = 0;      // WIFIRX_TEST_FAIL_ALLOC (allocation-failure tests)
+    int    test_fail_carry = 0, test_carry_count = 0;      // WIFIRX_TEST_FAIL_CARRY (a failure behind the commit of a stream pass)
+    bool   stream_dead = false;                            // the carry step failed after it had begun to move the sample buffer
+    std::string stream_dead_msg;
 
     // Host-buffer stream path (what a GNU Radio work() drives; wifirx_api_stream.inc): pushes are copied into one of two
     // pinned staging buffers of one batch each; a full one is handed to the worker thread, which runs the device
@@ -201,6 +204,7 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
     if (const char* e = std::getenv("WIFIRX_DECODE_Q")) h->decode_q = std::atoi(e) != 0;
     if (const char* e = std::getenv("WIFIRX_DECODE_OVL")) h->decode_ovl = std::atoi(e) != 0;
     if (const char* e = std::getenv("WIFIRX_TEST_FAIL_ALLOC")) h->test_fail_alloc = std::atoi(e);
+    if (const char* e = std::getenv("WIFIRX_TEST_FAIL_CARRY")) h->test_fail_carry = std::atoi(e);
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(nullptr, WIFIRX_EHIP, "hipStreamCreate failed");

@@ -48,6 +48,15 @@ namespace wr {
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
+#ifndef WR_X_LOOPS
+#define WR_X_LOOPS 1             // constellation loops with whole-line stores for the other output sets too (carrier, weights, moments, planes alone)
+#endif
+#ifndef WR_NT_LOADS
+#define WR_NT_LOADS 1            // the symbol loop's sample loads as non-temporal (streaming) loads
+#endif
+#ifndef WR_NT_STORES
+#define WR_NT_STORES 1           // store_bins_lines: the whole-line pieces as non-temporal stores
+#endif
 // LDS of the symbol loop, per wave (floats).  The scratch area at the front serves the FFT transposes (512 floats), the SIGNAL
 // decoder's survivor words, STA's window exchange and the staging of a symbol's output rows (store_bins_lines: 432 floats
 // for BPSK / QPSK rows, 1200 for 64-QAM = 4 x 1152 B of LLRs + 4 x 48 decisions).  The COMB instance keeps the short scratch
@@ -72,7 +81,11 @@ typedef float wr_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 load_global_f2(const float2* p)
 {
 #if WR_GLOBAL_SAMPLE_LOADS && defined(__HIP_DEVICE_COMPILE__)
+#if WR_NT_LOADS
+    const wr_f2 v = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) wr_f2*>(reinterpret_cast<uintptr_t>(p)));
+#else
     const wr_f2 v = *reinterpret_cast<const __attribute__((address_space(1))) wr_f2*>(reinterpret_cast<uintptr_t>(p));
+#endif
     return make_float2(v.x, v.y);
 #else
     return *p;
@@ -734,6 +747,25 @@ __device__ __forceinline__ void store_bins(const c32 (&Y)[4], const int (&carrie
     }
 }
 
+// a 16-byte piece / a dword of an output row (WR_NT_STORES: as a streaming store -- the rows are written once and never read here)
+typedef float wr_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_piece(char* p, float4 v)
+{
+#if WR_NT_STORES
+    __builtin_nontemporal_store(wr_f4v{ v.x, v.y, v.z, v.w }, reinterpret_cast<wr_f4v*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void store_word(uint8_t* p, uint32_t v)
+{
+#if WR_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(p));
+#else
+    *reinterpret_cast<uint32_t*>(p) = v;
+#endif
+}
+
 // The same stores as whole 16-byte pieces: a row's LLRs of one symbol are 192 NB contiguous bytes (192 / 384 / 768 / 1152)
 // and its decisions 48, but lane r holds bins r + 16 j, so store_bins() writes them as four pieces per row that start and end
 // inside 128-byte lines -- for 64-QAM as three 8-byte stores per bin with the lanes 24 bytes apart -- and the decisions as
@@ -807,12 +839,103 @@ __device__ __forceinline__ void store_bins_lines(const c32 (&Y)[4], const int (&
     __builtin_amdgcn_wave_barrier();
     if (ok) {
         char* lp = reinterpret_cast<char*>(llr) + (uint32_t)((row_l + (uint32_t)(q * 48 * NB)) * 4u + 16u * r);
-        if (NK > 1 || r < TAIL)            *reinterpret_cast<float4*>(lp) = p0;
-        if (NK > 2 || (NK == 2 && r < TAIL)) *reinterpret_cast<float4*>(lp + 256) = p1;
-        if (NK > 3 || (NK == 3 && r < TAIL)) *reinterpret_cast<float4*>(lp + 512) = p2;
-        if (NK > 4 || (NK == 4 && r < TAIL)) *reinterpret_cast<float4*>(lp + 768) = p3;
-        if (NK == 5 && r < TAIL)             *reinterpret_cast<float4*>(lp + 1024) = p4;
-        if (r < 12) *reinterpret_cast<uint32_t*>(idx + (row_o + (uint32_t)(q * 48) + 4u * r)) = d;
+        if (NK > 1 || r < TAIL)            store_piece(lp, p0);
+        if (NK > 2 || (NK == 2 && r < TAIL)) store_piece(lp + 256, p1);
+        if (NK > 3 || (NK == 3 && r < TAIL)) store_piece(lp + 512, p2);
+        if (NK > 4 || (NK == 4 && r < TAIL)) store_piece(lp + 768, p3);
+        if (NK == 5 && r < TAIL)             store_piece(lp + 1024, p4);
+        if (r < 12) store_word(idx + (row_o + (uint32_t)(q * 48) + 4u * r), d);
+    }
+}
+
+// The rows of a symbol as whole 16-byte pieces for ANY output set (round 4): decisions, LLRs -- with the channel-state weight
+// when asked for (spec rule 12) --, and the equalised points of the `carrier` port (IRS_AP.py:293: frame_equalizer.symbols; a row
+// of 48 points is 384 bytes = three whole lines).  Which outputs are wanted is wave-uniform and constant for the launch (scalar
+// branches); the constellation is compile time.  Same values, same addresses as store_bins().  For QPSK rows without weights the
+// LLR row IS the carrier row (re, im per carrier): the pieces are stored twice, not staged twice.
+// Requires (caller, wave-uniform): idx 4-byte, llr and car 16-byte aligned rows; has_llr = every active row wants LLRs.
+template <int NB>
+__device__ __forceinline__ void store_rows_x(const c32 (&Y)[4], const int (&carrier)[4], bool ok, int q,
+                                             uint8_t* __restrict__ idx, float* __restrict__ llr, float2* __restrict__ car,
+                                             bool has_idx, bool has_llr, bool has_car, bool csi, const float* Wl,
+                                             uint32_t row_o, uint32_t row_l, float* stage, int row, int r)
+{
+    static_assert(NB == 1 || NB == 2 || NB == 4 || NB == 6, "constellation");
+    constexpr int ROWB = 192 * NB, IDX0 = NB <= 2 ? 1536 : 4 * ROWB;
+    constexpr int NK = (12 * NB + 15) / 16, TAIL = 12 * NB - 16 * (NK - 1);
+    char* srow = reinterpret_cast<char*>(stage) + row * ROWB;
+    uint8_t* irow = reinterpret_cast<uint8_t*>(stage) + IDX0 + row * 48;
+    float4 p0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), p1 = p0;
+    if (has_idx || has_llr) {
+        float w[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+        if (csi) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = Wl[64 * j];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t row_bits = j == 0 ? 0xF7C0ull : j == 1 ? 0xFDFFull : j == 2 ? 0xFF7Eull : 0x07DFull;      // (the loop is unrolled)
+            if (!__builtin_amdgcn_inverse_ballot_w64(row_bits * 0x0001000100010001ull)) continue;
+            const float are = __builtin_fabsf(Y[j].re), aim = __builtin_fabsf(Y[j].im);
+            // (x * 1.0f is x for every float: the unweighted values are those of store_bins_lines)
+#define WR_WT(v) (csi ? (v) * w[j] : (v))
+            if (NB == 1)      *reinterpret_cast<float*>(srow + 4 * carrier[j]) = WR_WT(Y[j].re);
+            else if (NB == 2) *reinterpret_cast<float2*>(srow + 8 * carrier[j]) = make_float2(WR_WT(Y[j].re), WR_WT(Y[j].im));
+            else if (NB == 4) *reinterpret_cast<float4*>(srow + 16 * carrier[j]) = make_float4(WR_WT(Y[j].re), WR_WT(WR_T16_2 - are), WR_WT(Y[j].im), WR_WT(WR_T16_2 - aim));
+            else {
+                float2* l2 = reinterpret_cast<float2*>(srow + 24 * carrier[j]);
+                l2[0] = make_float2(WR_WT(Y[j].re), WR_WT(WR_T64_4 - are));
+                l2[1] = make_float2(WR_WT(WR_T64_2 - __builtin_fabsf(are - WR_T64_4)), WR_WT(Y[j].im));
+                l2[2] = make_float2(WR_WT(WR_T64_4 - aim), WR_WT(WR_T64_2 - __builtin_fabsf(aim - WR_T64_4)));
+            }
+#undef WR_WT
+            irow[carrier[j]] = decide(Y[j], NB);
+        }
+        __builtin_amdgcn_wave_barrier();
+#define WR_PIECE(k) (*reinterpret_cast<const float4*>(srow + 256 * (k) + 16 * (((k) == NK - 1 && TAIL == 8) ? (r & 7) : r)))
+        p0 = WR_PIECE(0);
+        float4 p2 = p0, p3 = p0, p4 = p0;
+        p1 = p0;
+        if (NK > 1) p1 = WR_PIECE(1);
+        if (NK > 2) p2 = WR_PIECE(2);
+        if (NK > 3) p3 = WR_PIECE(3);
+        if (NK > 4) p4 = WR_PIECE(4);
+#undef WR_PIECE
+        const uint32_t d = reinterpret_cast<const uint32_t*>(irow)[r < 12 ? r : 0];
+        __builtin_amdgcn_wave_barrier();
+        if (ok) {
+            if (has_llr) {
+                char* lp = reinterpret_cast<char*>(llr) + (uint32_t)((row_l + (uint32_t)(q * 48 * NB)) * 4u + 16u * r);
+                if (NK > 1 || r < TAIL)            store_piece(lp, p0);
+                if (NK > 2 || (NK == 2 && r < TAIL)) store_piece(lp + 256, p1);
+                if (NK > 3 || (NK == 3 && r < TAIL)) store_piece(lp + 512, p2);
+                if (NK > 4 || (NK == 4 && r < TAIL)) store_piece(lp + 768, p3);
+                if (NK == 5 && r < TAIL)             store_piece(lp + 1024, p4);
+            }
+            if (has_idx && r < 12) store_word(idx + (row_o + (uint32_t)(q * 48) + 4u * r), d);
+        }
+    }
+    if (has_car) {
+        if (!(NB == 2 && has_llr && !csi)) {       // (wave-uniform) the points staged on their own: 4 rows x 384 bytes
+            char* crow = reinterpret_cast<char*>(stage) + row * 384;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t row_bits = j == 0 ? 0xF7C0ull : j == 1 ? 0xFDFFull : j == 2 ? 0xFF7Eull : 0x07DFull;
+                if (!__builtin_amdgcn_inverse_ballot_w64(row_bits * 0x0001000100010001ull)) continue;
+                *reinterpret_cast<float2*>(crow + 8 * carrier[j]) = make_float2(Y[j].re, Y[j].im);
+            }
+            __builtin_amdgcn_wave_barrier();
+            p0 = *reinterpret_cast<const float4*>(crow + 16 * r);
+            p1 = *reinterpret_cast<const float4*>(crow + 256 + 16 * (r & 7));
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (ok) {
+            char* cp = reinterpret_cast<char*>(car) + (uint32_t)((row_o + (uint32_t)(q * 48)) * 8u + 16u * r);
+            store_piece(cp, p0);
+            if (r < 8) store_piece(cp + 256, p1);
+        }
     }
 }
 
@@ -1070,9 +1193,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     // NBC (compile time, data symbols only): > 0 = every row with data symbols carries this constellation AND the outputs are
     // the usual set (decisions + LLRs without weights, no equalised points): the store code is picked at compile time; 0 = decided
     // per symbol.
-    auto symbol = [&](auto data_c, auto nb_c, const int s) __attribute__((always_inline)) -> bool {
+    // XC (compile time, with NBC > 0): the rows leave through store_rows_x() -- any output set as whole lines (x_* below say which)
+    bool x_idx = false, x_llr = false, x_car = false, x_csi = false;     // wave-uniform, settled when the data symbols begin
+    auto symbol = [&](auto data_c, auto nb_c, auto x_c, const int s) __attribute__((always_inline)) -> bool {
         constexpr bool DATA = decltype(data_c)::value;
         constexpr int NBC = decltype(nb_c)::value;
+        constexpr bool XC = decltype(x_c)::value;
         const int off0 = fs + ((!DATA && s < 2) ? 64 * s : 128 + 80 * (s - 2) + 16);
         bool act;
         if (DATA) {
@@ -1424,7 +1550,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                   else     store_bins<NB, false>(Y, carrier, OK, q, idx, car, llr, has_idx, has_car, want_llr, w1, row_o, row_l); \
                   if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
                             store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
-                if (NBC != 0) {
+                if (NBC != 0 && XC) {
+                    store_rows_x<(NBC ? NBC : 1)>(Y, carrier, act, q, idx, llr, car, x_idx, x_llr, x_car, x_csi, Wl, row_o, row_l, qlds, row, r);
+                    if (HB) { __builtin_amdgcn_sched_barrier(0);
+                              store_hbits<(NBC ? NBC : 1)>(Y, act, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); }
+                } else if (NBC != 0) {
                     if (WR_STORE_AS_LINES && (NBC <= 2 || (WR_STORE_AS_LINES > 2 && !COMB)) && (!HB || WR_STORE_AS_LINES > 1) && lines_ok)
                         store_bins_lines<(NBC ? NBC : 1)>(Y, carrier, act, q, idx, llr, row_o, row_l, qlds, row, r);
                     else
@@ -1443,7 +1573,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                     WR_STORE(6, act && n_bpsc == 6)
                 }
 #undef WR_STORE
-                if (NBC == 0 && stat_all != nullptr) {     // (the constellation loops are entered only without it)
+                if ((NBC == 0 || XC) && stat_all != nullptr) {     // (the plain constellation loops are entered only without it)
                     // moments of the equalised points for the probe_mpsk_snr_est consumer (IRS_AP.py:275,312): per lane
                     // the data bins r + 16 j in ascending j (others 0), the row by the spec's xor tree, the frame symbol
                     // after symbol
@@ -1467,8 +1597,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         int s = 0;
         bool more = true;
         typedef std::integral_constant<int, 0> nb_any;
-        for (; more && s < 3; s++) more = symbol(std::false_type{}, nb_any{}, s);
+        typedef std::false_type no_x;
+        for (; more && s < 3; s++) more = symbol(std::false_type{}, nb_any{}, no_x{}, s);
 #if WR_SPLIT_SYMBOL_LOOP
+        uint64_t has_data = 0;
         if (more) {
             // the data symbols of a row: 3 .. n_sym + 2, as far as the copied samples (off0 + 64 <= L) and the output rows
             // (s - 3 < max_sym) go; a frame that is cut short is flagged here, once
@@ -1477,7 +1609,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             const bool cut = alive && s_lim < n_sym + 2;
             if (cut) { flags |= WIFIRX_F_TRUNCATED; alive = false; }
             s_end = (alive || cut) ? (cut ? s_lim : n_sym + 2) + 1 : 0;
-            const uint64_t has_data = __ballot(s_end > 3);
+            has_data = __ballot(s_end > 3);
             const int nb_first = has_data ? __builtin_amdgcn_readlane(n_bpsc, (int)__builtin_ctzll(has_data)) : 0;
             nbu_all = (has_data & ~__ballot(n_bpsc == nb_first)) == 0 ? nb_first : 0;
             // the usual output set: decisions + LLRs for every row with data symbols, no equalised points
@@ -1485,15 +1617,35 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         }
         const bool special = WR_NB_LOOPS && more && nbu_all > 0 && plain_all && !(prm.llr_csi != 0 && llr_all != nullptr) &&
                              lo_zero && stat_all == nullptr;      // wave-uniform
-        if (special && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, s);
-        else if (special && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, s);
-#if WR_NB_LOOPS > 1     // (not in the COMB instance: its scratch area is too short for these rows' line stores, and the loops alone cost it 6 %)
-        else if (!COMB && special && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, s);
-        else if (!COMB && special && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, s);
+#if WR_X_LOOPS
+        // any other output set of a wave whose rows share a constellation (round 4): the equalised points of the `carrier` port,
+        // weighted LLRs, the probe's moments, planes alone -- constellation loops with store_rows_x()
+        const uint64_t llr_rows = has_data & __ballot(want_llr);
+        const bool special_x = WR_NB_LOOPS && more && nbu_all > 0 && !special && lo_zero && (llr_rows == 0 || llr_rows == has_data) &&
+                               (reinterpret_cast<uintptr_t>(idx) & 3) == 0 && (reinterpret_cast<uintptr_t>(llr) & 15) == 0 &&
+                               (reinterpret_cast<uintptr_t>(car) & 15) == 0 && ((per * prm.llr_bits) & 3) == 0 && (per & 1) == 0;
+        x_idx = idx_all != nullptr;
+        x_llr = llr_rows != 0;
+        x_car = car_all != nullptr;
+        x_csi = prm.llr_csi != 0 && llr_all != nullptr;
+        typedef std::true_type with_x;
+        if (special_x && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, s);
+        else if (special_x && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, s);
+#if WR_NB_LOOPS > 1
+        else if (!COMB && special_x && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, s);
+        else if (!COMB && special_x && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, s);
 #endif
-        else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, s);
+        else
+#endif
+        if (special && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, no_x{}, s);
+        else if (special && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, no_x{}, s);
+#if WR_NB_LOOPS > 1     // (not in the COMB instance: its scratch area is too short for these rows' line stores, and the loops alone cost it 6 %)
+        else if (!COMB && special && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, no_x{}, s);
+        else if (!COMB && special && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, no_x{}, s);
+#endif
+        else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, no_x{}, s);
 #else
-        for (; more; s++) more = symbol(std::false_type{}, nb_any{}, s);
+        for (; more; s++) more = symbol(std::false_type{}, nb_any{}, no_x{}, s);
 #endif
     }
     if (r == 0 && out >= 0) {

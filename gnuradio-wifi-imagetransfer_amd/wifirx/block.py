@@ -144,9 +144,21 @@ class wifi_phy_rx(grshim.sync_block):
         return n
 
     def stop(self):
-        """End of stream: settle the frames still waiting for samples."""
-        self._rx._check(self._push(self._h, None, 0, 0))
-        self._publish()
+        """End of stream: settle the frames still waiting for samples.  A batch that failed on the library's worker thread is
+        reported by the first flush (once, before it does anything) and run again by the second: flush until it goes through
+        (at most three times), publish whatever is finished in any case, and only then -- with raise_on_error -- raise."""
+        rc = 0
+        try:
+            for _ in range(3):
+                rc = self._push(self._h, None, 0, 0)
+                if rc == 0:
+                    break
+                self.push_errors += 1
+                self.last_error = capi.lib().wifirx_last_error(self._h).decode()
+        finally:
+            self._publish()
+        if rc and self.raise_on_error:
+            self._rx._check(rc)
         return True
 
     def _publish(self):

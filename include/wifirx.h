@@ -124,7 +124,10 @@ typedef struct wifirx_config {
  * batches (n > batch size), which may have taken a prefix: repeat it from there.  Without a batch size a failed pass
  * is undone as a whole.  With one, the failure of a batch on the worker thread is reported by the NEXT push / flush
  * (once, before it takes anything); the failed batch stays staged in the library and the call after that runs it
- * again before going on. */
+ * again before going on.  A pass whose frames are queued is committed: a device failure behind that point (the carry of the
+ * samples a pending frame still needs) is never reported as a failed push.  If it struck before the sample buffer was
+ * touched, the stream goes on unharmed; if the buffer can no longer be trusted, every later push returns WIFIRX_EHIP
+ * with wifirx_push_consumed() = 0 and a text that says the stream is dead -- not a condition to retry: destroy the handle. */
 #define WIFIRX_P_STREAM_BATCH 5
 #define WIFIRX_STREAM_BATCH_MAX (1u << 27)
 /* decode_mac has two kernels with identical results: 128 frames per wave (throughput; a lone wave needs ~4 ms)

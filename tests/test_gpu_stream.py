@@ -348,3 +348,74 @@ def test_batch_calls_interleaved_with_a_stream_batch_in_flight(orc):
             if frames["flags"][i] & capi.F_CRC_OK:
                 assert np.array_equal(psdu[i, :L], opsdu[i, :L])
     rx.close()
+
+
+@pytest.mark.parametrize("batch", [0, 20000])
+def test_failure_behind_the_commit_of_a_pass_doubles_nothing(monkeypatch, batch):
+    """the carry step at the end of a stream pass runs AFTER the pass is committed (frames queued, fill and
+    frontier advanced).  A device failure there must not come back as a failed push -- every caller answers that by
+    handing the same samples in again, which would double them.  WIFIRX_TEST_FAIL_CARRY=k fails the k-th carry before it
+    has touched the sample buffer: no error, and exactly the frames of an undisturbed run, in the caller's thread
+    (batch = 0) and on the worker thread.  =-k fails it after the move began: the delivered frames stay, the stream is
+    dead, every later push says so with push_consumed() = 0 (include/wifirx.h, WIFIRX_P_STREAM_BATCH: ERRORS)."""
+    from wifirx import capi
+    x, _ = build_stream(seed=5)
+    ref_frames, ref_psdu = _ref_frames(x)
+    chunk = 4096                             # eleven passes (batch = 0) / three batches: several carries
+    for k in (1, 2, 3, 5):
+        monkeypatch.setenv("WIFIRX_TEST_FAIL_CARRY", str(k))
+        rx = capi.WifiRx(max_sym=511)
+        if batch:
+            rx.set_param(capi.P_STREAM_BATCH, batch)
+        got = []
+        for p in range(0, x.size, chunk):
+            rx.push(x[p:p + chunk])                     # never raises
+            assert rx.push_consumed() == min(chunk, x.size - p)
+            got.append(rx.poll(cap=64, want_idx=True))
+        rx.flush()
+        got.append(rx.poll(cap=64, want_idx=True))
+        rx.close()
+        assert np.array_equal(np.concatenate([g["frames"] for g in got]), ref_frames), k
+        assert np.array_equal(np.concatenate([g["psdu"] for g in got]), ref_psdu), k
+    monkeypatch.setenv("WIFIRX_TEST_FAIL_CARRY", "-2")
+    rx = capi.WifiRx(max_sym=511)
+    if batch:
+        rx.set_param(capi.P_STREAM_BATCH, batch)
+    got, dead_at = [], None
+    for p in range(0, x.size, chunk):
+        try:
+            rx.push(x[p:p + chunk])
+        except capi.WifiRxError as e:
+            assert e.code == -4 and "dead" in str(e) or "lost" in str(e)
+            assert rx.push_consumed() == 0
+            dead_at = p
+            break
+        got.append(rx.poll(cap=64, want_idx=True))
+    assert dead_at is not None
+    with pytest.raises(capi.WifiRxError):               # and it stays dead
+        rx.push(x[:chunk])
+    got.append(rx.poll(cap=64, want_idx=True))          # what was delivered before stays polled / pollable
+    rx.close()
+    frames = np.concatenate([g["frames"] for g in got])
+    assert len(frames) >= 1 and np.array_equal(frames, ref_frames[:len(frames)])
+
+
+def test_block_stop_flushes_and_publishes_through_a_pending_worker_error(monkeypatch):
+    """stop() used to raise on the worker's not-yet-reported error before flushing or publishing -- the frames
+    in the queue and the batch to be run again never reached mac_out, and raise_on_error = False was ignored.  One stop()
+    now settles everything; with raise_on_error the exception comes AFTER the PDUs are out."""
+    from wifirx import block, capi, grshim
+    x, psdus = build_stream(seed=5)
+    for raise_on_error in (False, True):
+        monkeypatch.setenv("WIFIRX_TEST_FAIL_ALLOC", "6")
+        blk = block.wifi_phy_rx(bandwidth=20e6, publish_carrier=False, batch_samples=1 << 22)     # one batch: it fails inside stop()'s flush
+        blk.raise_on_error = raise_on_error
+        got = []
+        grshim.msg_connect(blk, "mac_out", grshim.sink_block(got.append), "in")
+        assert grshim.run_stream(blk, x, chunk=4096, finish=False) == x.size
+        blk.stop()                                   # never raises here: the second flush runs the failed batch again
+        assert len(got) == len(psdus), (raise_on_error, len(got), blk.push_errors, blk.last_error)
+        assert blk.push_errors >= 1 and "hipMalloc" in blk.last_error
+        for (meta, blob), want in zip(got, psdus):
+            assert np.array_equal(np.asarray(blob), want[:-4])
+        blk.close()

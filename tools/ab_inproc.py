@@ -38,26 +38,35 @@ def main():
     ap.add_argument("--geometry", type=int, default=2)
     ap.add_argument("--eq", type=int, default=0)
     ap.add_argument("--planes", action="store_true")
+    ap.add_argument("--carrier", action="store_true", help="the equalised points too (want_carrier = 1: the reference's own output set)")
+    ap.add_argument("--planes-only", action="store_true", help="bit planes + records alone (what the stream path asks for)")
+    ap.add_argument("--csi", action="store_true", help="LLRs weighted by |H|^2 (WIFIRX_P_LLR_CSI)")
+    ap.add_argument("--stats", action="store_true", help="the probe's moments (sym_stats)")
     a = ap.parse_args()
     from wifirx import txgen
     enc, slot, snr = {2: (2, 4608, 20.0), 3: (7, 1472, 30.0), 1: (0, 8576, 20.0)}[a.geometry]
     tx = txgen.encode_psdus(txgen.make_psdus(64, 294, seed=5), enc)
     n_bpsc = txgen.RATE_TABLE[enc][0]
     mods = [load_capi(p, str(i)) for i, p in enumerate(a.libs)]
-    rxs = [m.WifiRx(max_sym=tx.n_sym, llr_bits=n_bpsc, chan_est=a.eq) for m in mods]
+    rxs = [m.WifiRx(max_sym=tx.n_sym, llr_bits=n_bpsc, chan_est=a.eq, want_carrier=a.carrier) for m in mods]
+    if a.csi:
+        for m, rx in zip(mods, rxs):
+            rx.set_param(m.P_LLR_CSI, 1)
     m0, rx0 = mods[0], rxs[0]
     n = a.frames
     iq = rx0.alloc(n * slot * 8)
     rx0.synth_slots(tx.samples, iq.ptr, slot, n, 160, snr, 0.037, 99)
-    dev = rx0.alloc_out(n, want_hbits=a.planes) if a.planes else rx0.alloc_out(n)
+    planes = a.planes or a.planes_only
+    dev = rx0.alloc_out(n, want_hbits=planes, want_stats=a.stats)
     rx0.sync()
     C = m0.C
     times = [[] for _ in rxs]
     for rnd in range(a.rounds):
         row = []
         for k, (m, rx) in enumerate(zip(mods, rxs)):
-            out = m.Out(dev["frames"].ptr, dev["idx"].ptr, dev["llr"].ptr, None, None, 0, 1, None, None,
-                        dev["hbits"].ptr if a.planes else None)
+            out = m.Out(dev["frames"].ptr, None if a.planes_only else dev["idx"].ptr, None if a.planes_only else dev["llr"].ptr,
+                        dev["carrier"].ptr if a.carrier else None, None, 0, 1, None,
+                        dev["sym_stats"].ptr if a.stats else None, dev["hbits"].ptr if planes else None)
             ms = C.c_float(0)
             best = 1e9
             for _ in range(3):
