@@ -167,7 +167,7 @@ def box_yardstick(iq_ptr, idx_ptr, llr_ptr, car_ptr, n_frames, slot_len, lead, n
     lib, sha, fresh = boxprobe_lib()
     if lib is None or not fresh:
         return {"available": False, "probe_src_sha": sha, "stale": lib is not None}
-    out = (C.c_double * 8)()
+    out = (C.c_double * 12)()
     rc = lib.boxprobe_run(iq_ptr, idx_ptr, llr_ptr, car_ptr, n_frames, slot_len, lead, n_sym, n_bpsc, reps, out)
     if rc != 0:
         return {"available": False, "probe_src_sha": sha, "hip_error": rc}
@@ -175,9 +175,12 @@ def box_yardstick(iq_ptr, idx_ptr, llr_ptr, car_ptr, n_frames, slot_len, lead, n
             "stream_tbps": out[1] / (out[0] * 1e-3) / 1e12, "stream_ms": out[0], "stream_gb": out[1] / 1e9,
             "mem_floor_ms": out[2], "symbols_only_ms": out[3], "loads_only_ms": out[4], "stores_only_ms": out[5],
             "pattern_gb": out[6] / 1e9,
+            "plain_loads_stores": {"mem_floor_ms": out[7], "stores_only_ms": out[8]},
+            "streaming_decisions_too": {"mem_floor_ms": out[9], "stores_only_ms": out[10]},
             "note": "same run, same process, the timed batch's own buffers: float4 stream at the kernel's read:write mix; "
                     "the demod kernel's global loads and stores without arithmetic (mem_floor = preamble reads + symbol "
-                    "loads + whole-line stores; loads / stores alone), best of %d launches each" % reps}
+                    "loads + whole-line stores; loads / stores alone; the kernel issues streaming (nt) sample loads and 16-byte pieces "
+                    "and plain decision dwords: the same patterns all plain and all streaming beside it), best of %d launches each" % reps}
 
 
 def ber_vs_tx(torch, idx_t, frames_np, tx, n_bpsc, capi):

@@ -87,6 +87,9 @@ struct wifirx_handle {
     void*  s_stats = nullptr;
     void*  s_hbits = nullptr;
     int    test_fail_alloc = 0, test_alloc_count = 0;      // WIFIRX_TEST_FAIL_ALLOC (allocation-failure tests)
+    size_t test_decode_budget = 0;                         // WIFIRX_TEST_DECODE_BUDGET: bytes of survivor scratch a decode call may hold (tests)
+    int    test_fail_decode_scratch = 0;                   // WIFIRX_TEST_FAIL_DECODE_SCRATCH: the next k scratch allocations fail (tests)
+    uint32_t dec_last_waves = 0; bool dec_last_overlap = false;      // what the last throughput decode ran with (WIFIRX_TRACE)
     int    test_fail_carry = 0, test_carry_count = 0;      // WIFIRX_TEST_FAIL_CARRY (a failure behind the commit of a stream pass)
     bool   stream_dead = false;                            // the carry step failed after it had begun to move the sample buffer
     std::string stream_dead_msg;
@@ -205,6 +208,8 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
     if (const char* e = std::getenv("WIFIRX_DECODE_OVL")) h->decode_ovl = std::atoi(e) != 0;
     if (const char* e = std::getenv("WIFIRX_TEST_FAIL_ALLOC")) h->test_fail_alloc = std::atoi(e);
     if (const char* e = std::getenv("WIFIRX_TEST_FAIL_CARRY")) h->test_fail_carry = std::atoi(e);
+    if (const char* e = std::getenv("WIFIRX_TEST_DECODE_BUDGET")) h->test_decode_budget = (size_t)std::strtoull(e, nullptr, 10);
+    if (const char* e = std::getenv("WIFIRX_TEST_FAIL_DECODE_SCRATCH")) h->test_fail_decode_scratch = std::atoi(e);
     if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(nullptr, WIFIRX_EHIP, "hipStreamCreate failed");

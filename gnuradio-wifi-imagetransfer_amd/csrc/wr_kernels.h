@@ -56,7 +56,22 @@ struct StreamTrig {
 
 }  // namespace wr
 
+// which translation unit's kernels a launch takes (wave-uniform facts the host knows): XK = any output set but decisions + LLRs
+static inline bool wr_demod_wants_x(const wr::DemodParams* prm, const wr::DemodOut* out)
+{
+#if defined(WR_X_LOOPS) && !WR_X_LOOPS
+    (void)prm; (void)out;
+    return false;
+#else
+    return out->carrier != nullptr || out->sym_stats != nullptr || out->idx == nullptr || out->llr == nullptr || prm->llr_csi != 0;
+#endif
+}
+
 extern "C" {
+hipError_t wr_launch_demod_batch_x(hipStream_t st, const float2* iq, uint32_t slot_len, uint32_t n_slots,
+                                   const wr::DemodParams* prm, const wr::DemodOut* out, const uint64_t* slot_off);
+hipError_t wr_launch_demod_stream_x(hipStream_t st, const float2* x, int64_t n_samp, const wr::StreamTrig* trig,
+                                    uint32_t n_trig, const wr::DemodParams* prm, const float2* A, const wr::DemodOut* out);
 hipError_t wr_launch_demod_batch(hipStream_t st, const float2* iq, uint32_t slot_len, uint32_t n_slots,
                                  const wr::DemodParams* prm, const wr::DemodOut* out, const uint64_t* slot_off);
 hipError_t wr_launch_synth(hipStream_t st, const float2* templates, uint32_t n_templates, uint32_t frame_len,

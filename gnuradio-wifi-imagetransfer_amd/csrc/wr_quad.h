@@ -48,6 +48,14 @@ namespace wr {
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
+#ifndef WR_X_COLD
+#define WR_X_COLD 0              // the loops of the other output sets are marked unlikely: the register allocator spills there, not in the timed loops
+#endif
+#if WR_X_COLD
+#define WR_UNLIKELY(c) __builtin_expect(!!(c), 0)
+#else
+#define WR_UNLIKELY(c) (c)
+#endif
 #ifndef WR_X_LOOPS
 #define WR_X_LOOPS 1             // constellation loops with whole-line stores for the other output sets too (carrier, weights, moments, planes alone)
 #endif
@@ -55,7 +63,7 @@ namespace wr {
 #define WR_NT_LOADS 1            // the symbol loop's sample loads as non-temporal (streaming) loads
 #endif
 #ifndef WR_NT_STORES
-#define WR_NT_STORES 1           // store_bins_lines: the whole-line pieces as non-temporal stores
+#define WR_NT_STORES 1           // store_bins_lines / store_rows_x: the whole-line 16-byte pieces as non-temporal stores (2: the decisions' dwords too -- slower)
 #endif
 // LDS of the symbol loop, per wave (floats).  The scratch area at the front serves the FFT transposes (512 floats), the SIGNAL
 // decoder's survivor words, STA's window exchange and the staging of a symbol's output rows (store_bins_lines: 432 floats
@@ -757,9 +765,13 @@ __device__ __forceinline__ void store_piece(char* p, float4 v)
     *reinterpret_cast<float4*>(p) = v;
 #endif
 }
+// a dword of a row's decisions: ALWAYS a plain store.  A row of decisions is 48 bytes -- never a whole 128-byte line --, and a
+// streaming store of part of a line leaves the L2 before the rest of the line has arrived: the memory probe's stores alone take
+// 6.5 ms with streaming decision dwords against 4.1 ms with plain ones on a box whose store path is slow, the whole pattern
+// 12.0 against 9.75 ms (bench.py roofline.box, profiles/r04_box_nt_decisions.json) -- the "slow box" of round 3's driver run.
 __device__ __forceinline__ void store_word(uint8_t* p, uint32_t v)
 {
-#if WR_NT_STORES
+#if WR_NT_STORES > 1
     __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(p));
 #else
     *reinterpret_cast<uint32_t*>(p) = v;
@@ -1046,7 +1058,9 @@ __device__ __forceinline__ c32 point_of(unsigned idx, int n_bpsc)
 // EQ = WIFIRX_EQ_STA:  spectral-temporal averaging of the per-bin estimates X/point.
 // HB: the decisions also leave as bit planes (DemodOut.hbits); a template parameter so that the kernels without planes
 // keep their register allocation.
-template <int EQ, bool HB>
+// XK: the kernel instance for every output set but decisions + LLRs (wr_kernels_x.hip): its constellation loops end in
+// store_rows_x(); the instance with XK = false keeps the loops of the usual set and nothing else (wr_demod.h).
+template <int EQ, bool HB, bool XK>
 __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodParams& prm, float* qlds, int lane,
                                             const DemodOut& dout)
 {
@@ -1615,9 +1629,10 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             // the usual output set: decisions + LLRs for every row with data symbols, no equalised points
             plain_all = WR_PLAIN_STORES && idx_all != nullptr && car_all == nullptr && (has_data & ~__ballot(want_llr)) == 0;
         }
-        const bool special = WR_NB_LOOPS && more && nbu_all > 0 && plain_all && !(prm.llr_csi != 0 && llr_all != nullptr) &&
+        const bool special = !XK && WR_NB_LOOPS && more && nbu_all > 0 && plain_all && !(prm.llr_csi != 0 && llr_all != nullptr) &&
                              lo_zero && stat_all == nullptr;      // wave-uniform
 #if WR_X_LOOPS
+      if constexpr (XK) {
         // any other output set of a wave whose rows share a constellation (round 4): the equalised points of the `carrier` port,
         // weighted LLRs, the probe's moments, planes alone -- constellation loops with store_rows_x()
         const uint64_t llr_rows = has_data & __ballot(want_llr);
@@ -1629,13 +1644,14 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         x_car = car_all != nullptr;
         x_csi = prm.llr_csi != 0 && llr_all != nullptr;
         typedef std::true_type with_x;
-        if (special_x && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, s);
-        else if (special_x && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, s);
+        if (WR_UNLIKELY(special_x && nbu_all == 1))      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, s);
+        else if (WR_UNLIKELY(special_x && nbu_all == 2)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, s);
 #if WR_NB_LOOPS > 1
-        else if (!COMB && special_x && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, s);
-        else if (!COMB && special_x && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, s);
+        else if (WR_UNLIKELY(!COMB && special_x && nbu_all == 4)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, s);
+        else if (WR_UNLIKELY(!COMB && special_x && nbu_all == 6)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, s);
 #endif
-        else
+        else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, no_x{}, s);
+      } else
 #endif
         if (special && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, no_x{}, s);
         else if (special && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, no_x{}, s);

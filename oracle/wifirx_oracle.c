@@ -56,9 +56,17 @@ typedef struct orc_params {
     int32_t lts_search;   /* SPEC mode only.  0: rule 6 as the kernels run it (candidates from the 8-bit search);
                            * 1: the float32 values of ALL 320 lags, the four largest of those -- sync_long's exhaustive
                            *    search in the spec's arithmetic.  The tests compare the two (tests/test_lts_rule6.py). */
-    int32_t pad_;
+    int32_t no_pair_fallback;  /* What sync_long does when no two of the four strongest lags are 64 / 63 / 65 apart.  0 (the build's
+                           * semantics): the frame is dropped.  1: upstream's -- d_frame_start keeps its
+                           * default, sync_length = 320, and d_freq_offset keeps the PREVIOUS frame's value (SURVEY App. A.3;
+                           * call site gnu_radio/IRS_AP.py:269,309): orc_demod_batch runs such frames again, in slot order,
+                           * with frame start 320 and the fine CFO of the last frame before them that found a pair (0 at
+                           * the start).  A measurement switch (tests/campaigns/lts_no_pair.py), not a product mode.
+                           * 2 (internal): this call IS such a re-run, fallback_cfo_f holds the value. */
     int32_t* dbg_top4;    /* test hook of orc_frame (single-threaded callers only): the four lags handed to the pair search */
     float*   dbg_mag4;    /* ... and their magnitudes (|corr|^2 in SPEC mode, |corr| in LIBM mode); NULL: off */
+    float    fallback_cfo_f;
+    int32_t  pad2_;
 } orc_params;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -808,7 +816,11 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
             }
         }
     }
-    if (!found) return;                                /* no LTS pair: frame dropped */
+    if (!found) {
+        if (prm->no_pair_fallback != 2) return;        /* no LTS pair: frame dropped */
+        fs = WIFIRX_SYNC_LENGTH;                       /* upstream: the default start and the previous frame's offset */
+        cfo_f = prm->fallback_cfo_f;
+    }
     fr->flags |= WIFIRX_F_SYNC;
     fr->frame_start = fs;
     fr->cfo_fine = cfo_f;
@@ -1234,6 +1246,26 @@ int orc_demod_batch(const c32* iq, uint32_t slot_len, uint32_t n_slots, const or
                   idx ? idx + i * idx_stride : NULL,
                   (llr && prm->llr_bits) ? llr + i * llr_stride : NULL,
                   eq ? eq + i * idx_stride : NULL, csi ? csi + (size_t)i * 52 : NULL);
+    }
+    if (prm->no_pair_fallback == 1) {
+        /* upstream's no-pair behaviour, measured: slot order = stream order */
+        orc_params p2 = *prm;
+        p2.no_pair_fallback = 2;
+        p2.dbg_top4 = NULL; p2.dbg_mag4 = NULL;
+        float last = 0.0f;
+        for (i = 0; i < (long)n_slots; i++) {
+            wifirx_frame* fr = frames + i;
+            if (fr->flags & WIFIRX_F_SYNC) { last = fr->cfo_fine; continue; }
+            if (!(fr->flags & WIFIRX_F_DETECTED) || (fr->flags & WIFIRX_F_TRUNCATED)) continue;
+            const c32* x = iq + (size_t)i * slot_len;
+            long L = (long)slot_len - (fr->trigger - 16);
+            if (L > WIFIRX_MAX_SAMPLES) L = WIFIRX_MAX_SAMPLES;
+            p2.fallback_cfo_f = last;
+            orc_frame(x, slot_len, fr->trigger, fr->cfo_coarse, L, &p2, fr,
+                      idx ? idx + i * idx_stride : NULL,
+                      (llr && prm->llr_bits) ? llr + i * llr_stride : NULL,
+                      eq ? eq + i * idx_stride : NULL, csi ? csi + (size_t)i * 52 : NULL);
+        }
     }
     return 0;
 }

@@ -197,8 +197,8 @@ def test_distance_to_upstream_literal_arithmetic_at_20ppm(orc):
 
 
 def _record(key, value):
-    """keeps what the tests measured: gpurun_out/r02_gpu_configs.json (copied to profiles/ by the builder)"""
-    path = os.path.join(ROOT, "gpurun_out", "r02_gpu_configs.json")
+    """keeps what the tests measured: gpurun_out/r04_gpu_configs.json (copied to profiles/ by the builder)"""
+    path = os.path.join(ROOT, "gpurun_out", "r04_gpu_configs.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         cur = {}

@@ -115,3 +115,44 @@ def test_decode_mac_four_frames_per_lane(capi, orc, monkeypatch, encoding, plen,
     assert np.array_equal(r["psdu"][dec][:, :plen], opsdu[dec][:, :plen])
     if snr >= 25:
         assert ((o["frames"]["flags"] & orc.F_CRC_OK) != 0).all() and np.array_equal(r["psdu"][:, :plen], tx.psdu)
+
+
+@pytest.mark.parametrize("fail_allocs,budget", [(1, 0), (2, 0), (4, 0), (0, 3_000_000), (0, 700_000)])
+def test_decode_mac_scratch_fallbacks(capi, orc, monkeypatch, fail_allocs, budget):
+    """the survivor scratch of the throughput decoder is sized from what the device has free and, when its
+    allocation fails all the same, retried without the overlap, then with half the waves, and again (the kernels are
+    grid-stride over their tasks) -- instead of returning ENOMEM for a batch that fits with fewer waves.  The test hooks fail
+    the next k scratch allocations / cap the budget; the PSDUs stay the oracle's, byte for byte."""
+    monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "0")
+    monkeypatch.setenv("WIFIRX_DECODE_Q", "1")
+    monkeypatch.setenv("WIFIRX_DECODE_FPW", "32")            # 1400 frames = 44 tasks: room to halve the waves several times
+    monkeypatch.setenv("WIFIRX_DECODE_OVL", "1")
+    if fail_allocs:
+        monkeypatch.setenv("WIFIRX_TEST_FAIL_DECODE_SCRATCH", str(fail_allocs))
+    if budget:
+        monkeypatch.setenv("WIFIRX_TEST_DECODE_BUDGET", str(budget))
+    n, plen = 1400, 120
+    iq, slot_len, tx = make_slots(n, 3, psdu_len=plen, snr_db=9.0, seed=77)
+    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=0)
+    r = rx.demod_batch(iq, slot_len, decode=True, psdu_stride=128)
+    rx.close()
+    prm = orc.make_params(max_sym=tx.n_sym)
+    o = orc.demod_batch(iq, slot_len, prm, n_threads=8)
+    opsdu = orc.decode_batch(o["frames"], o["idx"], prm, psdu_stride=128, n_threads=8)
+    assert np.array_equal(r["frames"], o["frames"])
+    dec = (o["frames"]["flags"] & orc.F_DECODED) != 0
+    assert dec.sum() > 1000
+    assert np.array_equal(r["psdu"][dec][:, :plen], opsdu[dec][:, :plen])
+
+
+def test_decode_mac_scratch_exhausted_is_enomem(capi, monkeypatch):
+    """... and when even 32 waves do not fit, the call says so (WIFIRX_ENOMEM), it does not crash or decode garbage"""
+    monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "0")
+    monkeypatch.setenv("WIFIRX_DECODE_FPW", "16")
+    monkeypatch.setenv("WIFIRX_TEST_FAIL_DECODE_SCRATCH", "50")
+    iq, slot_len, tx = make_slots(1400, 2, psdu_len=100, snr_db=25.0, seed=5)
+    rx = capi.WifiRx(max_sym=tx.n_sym, llr_bits=0)
+    with pytest.raises(capi.WifiRxError) as e:
+        rx.demod_batch(iq, slot_len, decode=True, psdu_stride=128)
+    assert e.value.code == -3
+    rx.close()

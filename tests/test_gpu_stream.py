@@ -382,13 +382,16 @@ def test_failure_behind_the_commit_of_a_pass_doubles_nothing(monkeypatch, batch)
     if batch:
         rx.set_param(capi.P_STREAM_BATCH, batch)
     got, dead_at = [], None
-    for p in range(0, x.size, chunk):
+    for p in list(range(0, x.size, chunk)) + [None]:        # the pushes, then the flush (a worker's failure is reported by the NEXT call)
         try:
-            rx.push(x[p:p + chunk])
+            if p is None:
+                rx.flush()
+            else:
+                rx.push(x[p:p + chunk])
         except capi.WifiRxError as e:
-            assert e.code == -4 and "dead" in str(e) or "lost" in str(e)
+            assert e.code == -4 and "lost" in str(e), str(e)
             assert rx.push_consumed() == 0
-            dead_at = p
+            dead_at = p if p is not None else x.size
             break
         got.append(rx.poll(cap=64, want_idx=True))
     assert dead_at is not None

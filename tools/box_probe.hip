@@ -14,6 +14,8 @@
 //   out[4] loads_ms      the symbol loop's loads alone
 //   out[5] stores_ms     the symbol loop's stores alone
 //   out[6] pattern_bytes the bytes the lanes of `combined` move
+//   out[7], out[8]       combined / stores alone with plain (temporal) loads and stores
+//   out[9], out[10]      combined / stores alone with everything streaming, the decisions' dwords too
 // every time the best of `reps` launches after one warm-up launch, HIP events on the null stream.
 // The rows it writes are garbage: bench.py calls it after its parity checks.
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/box_probe.hip -o tools/libboxprobe.so
@@ -37,34 +39,29 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 namespace {
 
-__device__ __forceinline__ float2 ld_sample(const float2* p)
+// NT: 1 = as the kernel issues them (streaming sample loads and 16-byte pieces, the decisions' dwords plain: csrc/wr_quad.h
+// store_word), 0 = all plain, 2 = everything streaming, the decisions' dwords too
+template <int NT> __device__ __forceinline__ float2 ld_sample(const float2* p)
 {
-#if BOXPROBE_NT_LOADS
-    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p));
-    return make_float2(v.x, v.y);
-#else
+    if (NT != 0 && BOXPROBE_NT_LOADS) {
+        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p));
+        return make_float2(v.x, v.y);
+    }
     return *p;
-#endif
 }
-__device__ __forceinline__ void st_piece(char* p, v4f v)
+template <int NT> __device__ __forceinline__ void st_piece(char* p, v4f v)
 {
-#if BOXPROBE_NT_STORES
-    __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
-#else
-    *reinterpret_cast<v4f*>(p) = v;
-#endif
+    if (NT != 0 && BOXPROBE_NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+    else *reinterpret_cast<v4f*>(p) = v;
 }
-__device__ __forceinline__ void st_word(uint8_t* p, uint32_t v)
+template <int NT> __device__ __forceinline__ void st_word(uint8_t* p, uint32_t v)
 {
-#if BOXPROBE_NT_STORES
-    __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(p));
-#else
-    *reinterpret_cast<uint32_t*>(p) = v;
-#endif
+    if (NT == 2 && BOXPROBE_NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(p));
+    else *reinterpret_cast<uint32_t*>(p) = v;
 }
 
 // NB: bits per sub-carrier (1, 2, 4, 6); CAR: the equalised points leave too (384 B per symbol and frame)
-template <int NB, int PRE, int LD, int ST, int CAR>
+template <int NB, int PRE, int LD, int ST, int CAR, int NT>
 __global__ __launch_bounds__(64, 4) void pattern(const float2* __restrict__ x, uint32_t n_slots, int slot_len, int lead,
                                                  int n_sym, uint8_t* __restrict__ idx, float* __restrict__ llr,
                                                  float2* __restrict__ car, float* sink)
@@ -96,7 +93,7 @@ __global__ __launch_bounds__(64, 4) void pattern(const float2* __restrict__ x, u
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             v[j] = make_float2((float)s, (float)j);
-            if (LD) v[j] = ld_sample(xs + off + r + 16 * j);
+            if (LD) v[j] = ld_sample<NT>(xs + off + r + 16 * j);
         }
         if (s >= 3 && ST) {
             const int q = s - 3;
@@ -104,12 +101,12 @@ __global__ __launch_bounds__(64, 4) void pattern(const float2* __restrict__ x, u
             char* d = lp + (size_t)q * (192 * NB);
 #pragma unroll
             for (int k = 0; k < NK; k++)
-                if (k < NK - 1 || r < TAIL) st_piece(d + 256 * k, w);
-            if (r < 12) st_word(ip + q * 48 + 4 * r, __float_as_uint(w.x + w.y));
+                if (k < NK - 1 || r < TAIL) st_piece<NT>(d + 256 * k, w);
+            if (r < 12) st_word<NT>(ip + q * 48 + 4 * r, __float_as_uint(w.x + w.y));
             if (CAR) {
                 char* c = cp + (size_t)q * 384;
-                st_piece(c, w);
-                if (r < 8) st_piece(c + 256, w);
+                st_piece<NT>(c, w);
+                if (r < 8) st_piece<NT>(c + 256, w);
             }
         } else {
 #pragma unroll
@@ -149,11 +146,17 @@ void run_patterns(const float2* x, uint32_t n, int slot_len, int lead, int n_sym
                   float* sink, int reps, hipEvent_t e0, hipEvent_t e1, double* out)
 {
     const dim3 g((n + 3) / 4), b(64);
-#define BP_RUN(PRE, LD, ST) best_of([&] { hipLaunchKernelGGL((pattern<NB, PRE, LD, ST, CAR>), g, b, 0, 0, x, n, slot_len, lead, n_sym, idx, llr, car, sink); }, reps, e0, e1)
-    out[2] = BP_RUN(1, 1, 1);
-    out[3] = BP_RUN(0, 1, 1);
-    out[4] = BP_RUN(0, 1, 0);
-    out[5] = BP_RUN(0, 0, 1);
+#define BP_RUN(PRE, LD, ST, NT) best_of([&] { hipLaunchKernelGGL((pattern<NB, PRE, LD, ST, CAR, NT>), g, b, 0, 0, x, n, slot_len, lead, n_sym, idx, llr, car, sink); }, reps, e0, e1)
+    out[2] = BP_RUN(1, 1, 1, 1);
+    out[3] = BP_RUN(0, 1, 1, 1);
+    out[4] = BP_RUN(0, 1, 0, 1);
+    out[5] = BP_RUN(0, 0, 1, 1);
+    // what the streaming (non-temporal) forms are worth on THIS box: the same patterns with plain loads and stores, and with
+    // the decisions' dwords (48 bytes per row: never a whole line) streaming too
+    out[7] = BP_RUN(1, 1, 1, 0);
+    out[8] = BP_RUN(0, 0, 1, 0);
+    out[9] = BP_RUN(1, 1, 1, 2);
+    out[10] = BP_RUN(0, 0, 1, 2);
 #undef BP_RUN
 }
 
