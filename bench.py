@@ -80,6 +80,7 @@ def parse_args(argv=None):
                     help="frame ranges the PDU all-gather is cut into (N > 1); 0 = as many as keep every range on decode_mac's "
                          "fastest kernel (>= 600 000 frames per range: one range for 1 M frames)")
     ap.add_argument("--host-samples", type=int, default=96_000_000, help="samples pushed through work() in the host_path leg")
+    ap.add_argument("--pipeline-batches", type=int, default=6, help="batches of the pipelined demod / decode_mac figure (0 = skip; N = 1 only)")
     ap.add_argument("--no-variants", action="store_true", help="skip the other geometries / output sets / equalisers")
     ap.add_argument("--variant-frames", type=int, default=0, help="frames per variant batch (0 = as --frames)")
     return ap.parse_args(argv)
@@ -505,7 +506,68 @@ def main():
         decode_range(0, n_frames, planes=False)
         rx.sync()
         dec_from_idx_ms = (time.perf_counter() - t3) * 1e3
-        pdu_leg = {"decode_mac_ms": float(np.median(dec_ms)),
+        # ---- the same two kernels pipelined: decode_mac of batch k on a second handle's stream while the demod of batch k + 1 runs
+        #      on the first one's; two sets of records / planes / PSDUs; BOTH timed together, wall clock over K batches ----
+        pipe = None
+        if not use_dist and args.pipeline_batches > 0:
+            import threading
+            K = args.pipeline_batches
+            rx2 = capi.WifiRx(bandwidth=BANDWIDTH, frequency=FREQUENCY, sensitivity=0.56, max_sym=n_sym, llr_bits=n_bpsc,
+                              want_carrier=False, device=local_rank)
+            frames2_t = torch.zeros_like(frames_t)
+            hbits2_t = torch.zeros_like(hbits_t)
+            psdu2_t = torch.zeros_like(psdu_t)
+            torch.cuda.synchronize()
+            sets = [(frames_t, hbits_t, psdu_t), (frames2_t, hbits2_t, psdu2_t)]
+            o_dem = [capi.Out(f.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), None, p_.data_ptr(), PSDU_STRIDE, 1, None, None, hb.data_ptr())
+                     for f, hb, p_ in sets]
+            o_dec = [capi.Out(f.data_ptr(), None, None, None, p_.data_ptr(), PSDU_STRIDE, 1, None, None, hb.data_ptr()) for f, hb, p_ in sets]
+            filled, free_ = threading.Semaphore(0), threading.Semaphore(2)
+            dem_ms, err = [], []
+
+            def producer(n):
+                try:
+                    for k in range(n):
+                        free_.acquire()
+                        dem_ms.append(demod(o_dem[k % 2]))          # returns when the kernel has finished (HIP events)
+                        filled.release()
+                except Exception as e:          # pragma: no cover
+                    err.append(e)
+                    filled.release()
+
+            def consumer(n):
+                try:
+                    for k in range(n):
+                        filled.acquire()
+                        rx2._check(capi.lib().wifirx_decode_batch(rx2._h, n_frames, capi.C.byref(o_dec[k % 2])))
+                        rx2.sync()
+                        free_.release()
+                except Exception as e:          # pragma: no cover
+                    err.append(e)
+                    free_.release()
+
+            def run_pipe(n):
+                ta, tb = threading.Thread(target=producer, args=(n,)), threading.Thread(target=consumer, args=(n,))
+                t_ = time.perf_counter()
+                ta.start(); tb.start(); ta.join(); tb.join()
+                return time.perf_counter() - t_
+
+            run_pipe(2)                           # first-call allocations of the second handle (its survivor scratch)
+            del dem_ms[:]
+            wall = run_pipe(K)
+            fr2 = frames2_t.cpu().numpy().view(capi.FRAME_DTYPE).reshape(-1)
+            pipe = {"batches": K, "ms_per_batch": wall / K * 1e3, "gsamples_per_s": float(n_frames) * SLOT_LEN * K / wall / 1e9,
+                    "demod_kernel_ms_under_decode": float(np.mean(dem_ms[1:])) if len(dem_ms) > 1 else None,
+                    "frames_crc_ok_second_set": int(((fr2["flags"] & capi.F_CRC_OK) != 0).sum()), "errors": [str(e) for e in err],
+                    "note": "two handles = two HIP streams: demod (idx + LLRs + planes) of batch k + 1 on one, decode_mac of batch k on "
+                            "the other, two sets of records / planes / PSDUs, host threads hand the sets over; wall clock over all "
+                            "batches, both kernels timed together"}
+            rx2.close()
+            del frames2_t, hbits2_t, psdu2_t
+            demod(out_hb)                         # the first set as the serial configuration leaves it
+            decode_range(0, n_frames)
+            rx.sync()
+        pdu_leg = {"decode_mac_ms": float(np.median(dec_ms)), "pipelined": pipe,
                    "demod_with_planes_ms": demod_planes_ms, "decode_mac_from_idx_ms": dec_from_idx_ms,
                    "demod_planes_only_ms": demod_pdu_only_ms,
                    "all_gather_ms": ag_alone, "all_gather_exposed_ms": float(np.median(ag_ms)) if use_dist else None,
@@ -606,6 +668,8 @@ def main():
             t_pair = pdu_leg["demod_with_planes_ms"] + pdu_leg["decode_mac_ms"]
             result["samples_to_pdu"] = {"demod_ms": pdu_leg["demod_with_planes_ms"], "decode_mac_ms": pdu_leg["decode_mac_ms"],
                                         "gsamples_per_s": float(n_frames) * SLOT_LEN / (t_pair * 1e-3) / 1e9,
+                                        "pipelined_gsamples_per_s": pdu_leg["pipelined"]["gsamples_per_s"] if pdu_leg.get("pipelined") else None,
+                                        "pipelined_ms_per_batch": pdu_leg["pipelined"]["ms_per_batch"] if pdu_leg.get("pipelined") else None,
                                         "pdu_only_demod_ms": pdu_leg["demod_planes_only_ms"],
                                         "pdu_only_gsamples_per_s": float(n_frames) * SLOT_LEN /
                                                                    ((pdu_leg["demod_planes_only_ms"] + pdu_leg["decode_mac_ms"]) * 1e-3) / 1e9,

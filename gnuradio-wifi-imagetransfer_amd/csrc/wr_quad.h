@@ -48,6 +48,10 @@ namespace wr {
 #ifndef WR_GLOBAL_SAMPLE_LOADS
 #define WR_GLOBAL_SAMPLE_LOADS 1
 #endif
+#ifndef WR_DMA_PREFETCH
+#define WR_DMA_PREFETCH 1        // BPSK / QPSK loops of the usual output set: the next symbol's samples by LDS-DMA (global_load_lds_dwordx4), requested while this symbol is computed
+#endif
+#define WR_QLDS_PFX (WR_DMA_PREFETCH ? 256 : 0)       // floats behind the LLR-weight area that complete the 2-kB prefetch buffer (4 frames x 64 samples x 8 B)
 #ifndef WR_X_COLD
 #define WR_X_COLD 0              // the loops of the other output sets are marked unlikely: the register allocator spills there, not in the timed loops
 #endif
@@ -78,7 +82,8 @@ namespace wr {
 #define WR_QLDS_TW(S)      (WR_QLDS_H(S) + 512)       // 6 x 16 float2: stage-1/2 twiddles by row lane
 #define WR_QLDS_PREV(S)    (WR_QLDS_TW(S) + 192)      // 4 rows x 4 float2: pilots of the previous symbol
 #define WR_QLDS_W(S)       (WR_QLDS_PREV(S) + 32)     // 4 x 64 floats: |H|^2 of the LS estimate (LLR weight, lane-private slots)
-#define WR_QLDS_STAT(S)    (WR_QLDS_W(S) + 256)       // 4 rows x 4 floats: running sums of |y|, |y|^2, |y|^4 (sym_stats output)
+#define WR_QLDS_PF(S)      (WR_QLDS_W(S))             // the prefetch buffer of the usual output set's loops: the weight area (idle there: weights are an XK output) + WR_QLDS_PFX
+#define WR_QLDS_STAT(S)    (WR_QLDS_W(S) + 256 + WR_QLDS_PFX)       // 4 rows x 4 floats: running sums of |y|, |y|^2, |y|^4 (sym_stats output)
 #define WR_QLDS_FLOATS(S)  (WR_QLDS_STAT(S) + 16)     // per wave; the preamble phase uses the first 1536 floats for two frames' samples
 #define WR_QLDS_DH(S)      (WR_QLDS_FLOATS(S))        // COMB only: 4 x 64 float2, the running estimate d_H
 #define WR_QLDS_FLOATS_EQ(EQ) (WR_QLDS_FLOATS(WR_QLDS_SCRATCH_EQ(EQ)) + ((EQ) == WIFIRX_EQ_COMB ? 512 : 0))
@@ -95,6 +100,17 @@ __device__ __forceinline__ float2 load_global_f2(const float2* p)
     const wr_f2 v = *reinterpret_cast<const __attribute__((address_space(1))) wr_f2*>(reinterpret_cast<uintptr_t>(p));
 #endif
     return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+
+// a wave-uniform float of a constant table through the scalar data cache (s_load_dword: counted on lgkmcnt, not on the vector
+// memory counter the LDS-DMA prefetch waits on)
+__device__ __forceinline__ float load_const_f(const float* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const __attribute__((address_space(4))) float*>(reinterpret_cast<uintptr_t>(p));
 #else
     return *p;
 #endif
@@ -1209,10 +1225,26 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     // per symbol.
     // XC (compile time, with NBC > 0): the rows leave through store_rows_x() -- any output set as whole lines (x_* below say which)
     bool x_idx = false, x_llr = false, x_car = false, x_csi = false;     // wave-uniform, settled when the data symbols begin
-    auto symbol = [&](auto data_c, auto nb_c, auto x_c, const int s) __attribute__((always_inline)) -> bool {
+    // PC (compile time, BPSK / QPSK loops of the usual output set): the samples of a symbol arrive by LDS-DMA, requested one symbol
+    // ahead (pf_* below); the wave waits for them with a COUNTED s_waitcnt that leaves the stores of the symbol before in flight.
+    uint32_t pf_voff0 = 0, pf_voff1 = 0;         // byte offsets of this lane's 16 bytes (frames 0 / 1 and 2 / 3) from pf_next
+    const float2* pf_next = nullptr;             // wave-uniform: first sample of the NEXT symbol of the reference row
+    int pf_end = 0;                              // the symbol index at which every row with data symbols ends
+    // LDS byte address of the buffer and of its second half (wave-uniform: in scalar registers, whatever the compiler can prove)
+    const uint32_t pf_m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(qlds + WR_QLDS_PF(QS)));
+    const uint32_t pf_m1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pf_m0 + 1024u));
+    auto pf_issue = [&](float dep) __attribute__((always_inline)) {
+        // two instructions of 1 kB: lanes 0..31 -> 64 samples of frame 0 (2), lanes 32..63 -> frame 1 (3); LDS address = M0 + 16 lane
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+                     "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4"
+                     :: "s"(pf_m0), "s"(pf_m1), "v"(pf_voff0), "v"(pf_voff1), "s"(pf_next), "v"(dep) : "memory");
+        pf_next += 80;
+    };
+    auto symbol = [&](auto data_c, auto nb_c, auto x_c, auto p_c, const int s) __attribute__((always_inline)) -> bool {
         constexpr bool DATA = decltype(data_c)::value;
         constexpr int NBC = decltype(nb_c)::value;
         constexpr bool XC = decltype(x_c)::value;
+        constexpr bool PC = decltype(p_c)::value;
         const int off0 = fs + ((!DATA && s < 2) ? 64 * s : 128 + 80 * (s - 2) + 16);
         bool act;
         if (DATA) {
@@ -1230,6 +1262,19 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         // ---- samples r + 16 j of the symbol (rows without a symbol get zeros) ----
         c32 v[4], cur[4];
         {
+            if (PC) {
+                // the DMA of this symbol's samples was issued before the stores of the symbol before: NK pieces + one dword of
+                // decisions (+ the stores of the plane words: 1 / 1 / 2 / 3) may still be in flight behind it (the counter is in order)
+#ifdef WR_PF_WAIT_ALL
+                constexpr int NST = 0;
+#else
+                constexpr int NST = (12 * (NBC ? NBC : 1) + 15) / 16 + 1 + (HB ? ((NBC ? NBC : 1) + 1) / 2 : 0);
+#endif
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
+                const float2* pb = reinterpret_cast<const float2*>(qlds + WR_QLDS_PF(QS)) + 64 * row + r;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const float2 t = pb[16 * j]; cur[j] = { t.x, t.y }; }
+            } else
             if (NBC != 0 || lo_zero) {  // act => off0 + 63 < L <= m_hi: every sample of the symbol is in range (the constellation loops are entered only then)
                 // rows without a symbol read the first 64 samples of their (or the wave's first) frame instead: finite
                 // numbers that no output sees -- cheaper than zeroing eight registers per symbol for them
@@ -1255,6 +1300,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 v[j] = sp_cmul(cur[j], w);                         // rows without a symbol loaded zeros above
                 w = sp_cmul(w, u16);
             }
+            // the buffer has been read (the products above used it): the next symbol's samples may land in it
+            if (PC && s + 1 < pf_end) pf_issue(v[3].re);
         }
         // ---- FFT-64: three in-register radix-4 stages, two transposes through LDS ----
         bfly4_reg(v[0], v[1], v[2], v[3]);
@@ -1295,7 +1342,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             // float32 table, eps0 and d_er are float32
             const float kf = t4 * (eps0 + d_er);
 #if WR_T4_POINTER
-            if (DATA) { t4 = *t4_next; t4_next++; }             // the next symbol's factor (s + 1 <= 514: inside the table), requested a whole iteration early
+            if (DATA) { t4 = PC ? load_const_f(t4_next) : *t4_next; t4_next++; }             // the next symbol's factor (s + 1 <= 514: inside the table), requested a whole iteration early
             else { t4 = WR_T4_64F[s + 1]; t4_next = WR_T4_64F + (s + 2); }
 #else
             t4 = WR_T4_64F[s < 518 ? s + 1 : 519];              // the next symbol's factor: requested a whole iteration early
@@ -1569,7 +1616,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                     if (HB) { __builtin_amdgcn_sched_barrier(0);
                               store_hbits<(NBC ? NBC : 1)>(Y, act, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); }
                 } else if (NBC != 0) {
-                    if (WR_STORE_AS_LINES && (NBC <= 2 || (WR_STORE_AS_LINES > 2 && !COMB)) && (!HB || WR_STORE_AS_LINES > 1) && lines_ok)
+                    if (WR_STORE_AS_LINES && (NBC <= 2 || (WR_STORE_AS_LINES > 2 && !COMB)) && (!HB || WR_STORE_AS_LINES > 1) && (PC || lines_ok))     // (a prefetch loop is entered only with lines_ok)
                         store_bins_lines<(NBC ? NBC : 1)>(Y, carrier, act, q, idx, llr, row_o, row_l, qlds, row, r);
                     else
                     store_bins<(NBC ? NBC : 1), false, true>(Y, carrier, act, q, idx, car, llr, true, false, true, w1, row_o, row_l);
@@ -1612,7 +1659,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         bool more = true;
         typedef std::integral_constant<int, 0> nb_any;
         typedef std::false_type no_x;
-        for (; more && s < 3; s++) more = symbol(std::false_type{}, nb_any{}, no_x{}, s);
+        typedef std::false_type no_p;
+        for (; more && s < 3; s++) more = symbol(std::false_type{}, nb_any{}, no_x{}, no_p{}, s);
 #if WR_SPLIT_SYMBOL_LOOP
         uint64_t has_data = 0;
         if (more) {
@@ -1644,24 +1692,62 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         x_car = car_all != nullptr;
         x_csi = prm.llr_csi != 0 && llr_all != nullptr;
         typedef std::true_type with_x;
-        if (WR_UNLIKELY(special_x && nbu_all == 1))      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, s);
-        else if (WR_UNLIKELY(special_x && nbu_all == 2)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, s);
+        if (WR_UNLIKELY(special_x && nbu_all == 1))      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, no_p{}, s);
+        else if (WR_UNLIKELY(special_x && nbu_all == 2)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, no_p{}, s);
 #if WR_NB_LOOPS > 1
-        else if (WR_UNLIKELY(!COMB && special_x && nbu_all == 4)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, s);
-        else if (WR_UNLIKELY(!COMB && special_x && nbu_all == 6)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, s);
+        else if (WR_UNLIKELY(!COMB && special_x && nbu_all == 4)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, no_p{}, s);
+        else if (WR_UNLIKELY(!COMB && special_x && nbu_all == 6)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, no_p{}, s);
 #endif
-        else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, no_x{}, s);
+        else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, no_x{}, no_p{}, s);
       } else
 #endif
-        if (special && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, no_x{}, s);
-        else if (special && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, no_x{}, s);
-#if WR_NB_LOOPS > 1     // (not in the COMB instance: its scratch area is too short for these rows' line stores, and the loops alone cost it 6 %)
-        else if (!COMB && special && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, no_x{}, s);
-        else if (!COMB && special && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, no_x{}, s);
+      {
+#if WR_DMA_PREFETCH
+        // The samples by LDS-DMA, one symbol ahead: when every row with data symbols ends at the same symbol, the rows leave as
+        // whole lines (the store count the wait relies on), and the rows' samples lie within 2^30 bytes above the first row's.
+        bool pf = false;
+        if (special && (!COMB || nbu_all <= 2) && lines_ok) {        // wave-uniform
+            const int first = (int)__builtin_ctzll(has_data);
+            const bool mine = s_end > 3;
+            pf_end = __builtin_amdgcn_readlane(s_end, first);
+            const uint64_t xbv = reinterpret_cast<uint64_t>(xb);
+            const uint64_t xref = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(xbv >> 32), first) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)xbv, first);
+            const int64_t dist = (int64_t)(xbv - xref) / (int64_t)sizeof(float2);        // samples
+            pf = __all(!mine || (s_end == pf_end && dist >= 0 && dist < (1 << 26)));
+            if (pf) {
+                const int c_own = (int)dist + fs;
+                const int c_ref = __builtin_amdgcn_readlane(c_own, first);
+                const int c = mine ? c_own : c_ref;                  // rows without data symbols read the reference row's samples
+                const int c0 = __builtin_amdgcn_readlane(c, 0), c1 = __builtin_amdgcn_readlane(c, 16);
+                const int c2 = __builtin_amdgcn_readlane(c, 32), c3 = __builtin_amdgcn_readlane(c, 48);
+                pf_voff0 = (uint32_t)((lane < 32 ? c0 : c1) + 2 * (lane & 31)) * 8u;
+                pf_voff1 = (uint32_t)((lane < 32 ? c2 : c3) + 2 * (lane & 31)) * 8u;
+                pf_next = reinterpret_cast<const float2*>(xref) + (128 + 80 * (s - 2) + 16);
+                __builtin_amdgcn_wave_barrier();
+                pf_issue(0.0f);                                      // the first data symbol's samples: nothing to hide behind yet, and
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no stores behind them that the loop's counted wait could count on
+            }
+        }
+        typedef std::true_type with_p;
+        if (pf && nbu_all == 1)           for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, no_x{}, with_p{}, s);
+        else if (pf && nbu_all == 2)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, no_x{}, with_p{}, s);
+#if WR_NB_LOOPS > 1
+        else if (!COMB && pf && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, no_x{}, with_p{}, s);
+        else if (!COMB && pf && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, no_x{}, with_p{}, s);
 #endif
-        else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, no_x{}, s);
+        else
+#endif
+        if (special && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, no_x{}, no_p{}, s);
+        else if (special && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, no_x{}, no_p{}, s);
+#if WR_NB_LOOPS > 1     // (not in the COMB instance: its scratch area is too short for these rows' line stores, and the loops alone cost it 6 %)
+        else if (!COMB && special && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, no_x{}, no_p{}, s);
+        else if (!COMB && special && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, no_x{}, no_p{}, s);
+#endif
+        else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, no_x{}, no_p{}, s);
+      }
 #else
-        for (; more; s++) more = symbol(std::false_type{}, nb_any{}, no_x{}, s);
+        for (; more; s++) more = symbol(std::false_type{}, nb_any{}, no_x{}, no_p{}, s);
 #endif
     }
     if (r == 0 && out >= 0) {

@@ -125,7 +125,7 @@ def test_decode_mac_scratch_fallbacks(capi, orc, monkeypatch, fail_allocs, budge
     the next k scratch allocations / cap the budget; the PSDUs stay the oracle's, byte for byte."""
     monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "0")
     monkeypatch.setenv("WIFIRX_DECODE_Q", "1")
-    monkeypatch.setenv("WIFIRX_DECODE_FPW", "32")            # 1400 frames = 44 tasks: room to halve the waves several times
+    monkeypatch.setenv("WIFIRX_DECODE_FPW", "16")            # 1400 frames = 88 tasks: room to halve the waves several times
     monkeypatch.setenv("WIFIRX_DECODE_OVL", "1")
     if fail_allocs:
         monkeypatch.setenv("WIFIRX_TEST_FAIL_DECODE_SCRATCH", str(fail_allocs))
@@ -146,7 +146,7 @@ def test_decode_mac_scratch_fallbacks(capi, orc, monkeypatch, fail_allocs, budge
 
 
 def test_decode_mac_scratch_exhausted_is_enomem(capi, monkeypatch):
-    """... and when even 32 waves do not fit, the call says so (WIFIRX_ENOMEM), it does not crash or decode garbage"""
+    """... and when even four waves do not fit, the call says so (WIFIRX_ENOMEM), it does not crash or decode garbage"""
     monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "0")
     monkeypatch.setenv("WIFIRX_DECODE_FPW", "16")
     monkeypatch.setenv("WIFIRX_TEST_FAIL_DECODE_SCRATCH", "50")

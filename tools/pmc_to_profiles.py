@@ -35,7 +35,7 @@ def main():
             for c in sorted(acc[k]):
                 v = acc[k][c]
                 out.write("\"%s\",%s,%.6g,%d\n" % (k, c, sum(v) / len(v), len(v)))
-    dom = "wr::demod_batch_kernel<0, false>"            # the timed kernel of bench.py: LS equaliser, no plane output
+    dom = "wr::demod_batch_kernel<0, false, false>"            # the timed kernel of bench.py: LS equaliser, no plane output
     d = {c: sum(v) / len(v) for c, v in acc[dom].items()}
     corr = 2.0
     rd, wr = d["FETCH_SIZE"] * 1024 * corr, d["WRITE_SIZE"] * 1024
