@@ -127,6 +127,10 @@ def latest_profile(suffix):
 def device_clocks():
     """rocm-smi's view of the device clocks, read BEFORE this process touches the GPU (a child process; nothing here
     initialises HIP).  None when the tool is missing or refuses."""
+    # under rocprofv3 the profiler's preloaded library has initialised the GPU before Python starts, and a child that execs
+    # from such a process is refused on this pool: no child processes then
+    if os.environ.get("LD_PRELOAD") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return {"skipped": "profiler loaded"}
     try:
         r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, timeout=20, text=True)
         j = json.loads(r.stdout)
