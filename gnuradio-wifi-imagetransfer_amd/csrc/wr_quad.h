@@ -1230,6 +1230,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     uint32_t pf_voff0 = 0, pf_voff1 = 0;         // byte offsets of this lane's 16 bytes (frames 0 / 1 and 2 / 3) from pf_next
     const float2* pf_next = nullptr;             // wave-uniform: first sample of the NEXT symbol of the reference row
     int pf_end = 0;                              // the symbol index at which every row with data symbols ends
+    int pf_nst = 0;                              // XK instances: global stores one symbol issues (wave-uniform, constant for the launch)
     // LDS byte address of the buffer and of its second half (wave-uniform: in scalar registers, whatever the compiler can prove)
     const uint32_t pf_m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(qlds + WR_QLDS_PF(QS)));
     const uint32_t pf_m1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pf_m0 + 1024u));
@@ -1239,6 +1240,30 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                      "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4"
                      :: "s"(pf_m0), "s"(pf_m1), "v"(pf_voff0), "v"(pf_voff1), "s"(pf_next), "v"(dep) : "memory");
         pf_next += 80;
+    };
+    // Can the data loop that begins at symbol s0 take the prefetch?  Every row with data symbols must end at the same symbol and
+    // its samples lie within 2^29 bytes above the first such row's.  Sets the lanes' offsets up and requests the first symbol.
+    auto pf_setup = [&](uint64_t has_data, int s0) __attribute__((always_inline)) -> bool {
+        const int first = (int)__builtin_ctzll(has_data);
+        const bool mine = s_end > 3;
+        pf_end = __builtin_amdgcn_readlane(s_end, first);
+        const uint64_t xbv = reinterpret_cast<uint64_t>(xb);
+        const uint64_t xref = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(xbv >> 32), first) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)xbv, first);
+        const int64_t dist = (int64_t)(xbv - xref) / (int64_t)sizeof(float2);        // samples
+        if (!__all(!mine || (s_end == pf_end && dist >= 0 && dist < (1 << 26)))) return false;
+        const int c_own = (int)dist + fs;
+        const int c_ref = __builtin_amdgcn_readlane(c_own, first);
+        const int c = mine ? c_own : c_ref;                  // rows without data symbols read the reference row's samples
+        const int c0 = __builtin_amdgcn_readlane(c, 0), c1 = __builtin_amdgcn_readlane(c, 16);
+        const int c2 = __builtin_amdgcn_readlane(c, 32), c3 = __builtin_amdgcn_readlane(c, 48);
+        pf_voff0 = (uint32_t)((lane < 32 ? c0 : c1) + 2 * (lane & 31)) * 8u;
+        pf_voff1 = (uint32_t)((lane < 32 ? c2 : c3) + 2 * (lane & 31)) * 8u;
+        pf_next = reinterpret_cast<const float2*>(xref) + (128 + 80 * (s0 - 2) + 16);
+        __builtin_amdgcn_wave_barrier();
+        pf_issue(0.0f);                                      // the first data symbol's samples: nothing to hide behind yet, and
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no stores behind them that the loop's counted wait could count on
+        return true;
     };
     auto symbol = [&](auto data_c, auto nb_c, auto x_c, auto p_c, const int s) __attribute__((always_inline)) -> bool {
         constexpr bool DATA = decltype(data_c)::value;
@@ -1270,6 +1295,16 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #else
                 constexpr int NST = (12 * (NBC ? NBC : 1) + 15) / 16 + 1 + (HB ? ((NBC ? NBC : 1) + 1) / 2 : 0);
 #endif
+                if (XC) {
+                    // the XK instances: how many stores a symbol issues is a constant of the launch (which outputs are wanted),
+                    // not of the instance -- the immediate of the wait is picked by a scalar switch
+                    switch (pf_nst) {
+#define WR_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+                    WR_W(1) WR_W(2) WR_W(3) WR_W(4) WR_W(5) WR_W(6) WR_W(7) WR_W(8) WR_W(9) WR_W(10) WR_W(11)
+#undef WR_W
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    }
+                } else
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
                 const float2* pb = reinterpret_cast<const float2*>(qlds + WR_QLDS_PF(QS)) + 64 * row + r;
 #pragma unroll
@@ -1692,6 +1727,24 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         x_car = car_all != nullptr;
         x_csi = prm.llr_csi != 0 && llr_all != nullptr;
         typedef std::true_type with_x;
+#if WR_DMA_PREFETCH
+        // ... with the samples by LDS-DMA when the weight area is idle (no weighted LLRs) and every row ends at the same symbol
+        bool pfx = false;
+        // (... and LLR or point rows are written: with the planes alone the wait has next to nothing to skip, 9.99 vs 10.06 ms)
+        if (special_x && !x_csi && (x_llr || x_car) && (!COMB || nbu_all <= 2)) {
+            pfx = pf_setup(has_data, s);
+            const int nk = (12 * nbu_all + 15) / 16;
+            pf_nst = (x_llr ? nk : 0) + (x_idx ? 1 : 0) + (x_car ? 2 : 0) + (HB ? (nbu_all + 1) / 2 : 0);
+        }
+        typedef std::true_type with_px;
+        if (pfx && nbu_all == 1)           for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, with_px{}, s);
+        else if (pfx && nbu_all == 2)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, with_px{}, s);
+#if WR_NB_LOOPS > 1
+        else if (!COMB && pfx && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, with_px{}, s);
+        else if (!COMB && pfx && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, with_px{}, s);
+#endif
+        else
+#endif
         if (WR_UNLIKELY(special_x && nbu_all == 1))      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, no_p{}, s);
         else if (WR_UNLIKELY(special_x && nbu_all == 2)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, no_p{}, s);
 #if WR_NB_LOOPS > 1
@@ -1706,29 +1759,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         // The samples by LDS-DMA, one symbol ahead: when every row with data symbols ends at the same symbol, the rows leave as
         // whole lines (the store count the wait relies on), and the rows' samples lie within 2^30 bytes above the first row's.
         bool pf = false;
-        if (special && (!COMB || nbu_all <= 2) && lines_ok) {        // wave-uniform
-            const int first = (int)__builtin_ctzll(has_data);
-            const bool mine = s_end > 3;
-            pf_end = __builtin_amdgcn_readlane(s_end, first);
-            const uint64_t xbv = reinterpret_cast<uint64_t>(xb);
-            const uint64_t xref = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(xbv >> 32), first) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readlane((int)xbv, first);
-            const int64_t dist = (int64_t)(xbv - xref) / (int64_t)sizeof(float2);        // samples
-            pf = __all(!mine || (s_end == pf_end && dist >= 0 && dist < (1 << 26)));
-            if (pf) {
-                const int c_own = (int)dist + fs;
-                const int c_ref = __builtin_amdgcn_readlane(c_own, first);
-                const int c = mine ? c_own : c_ref;                  // rows without data symbols read the reference row's samples
-                const int c0 = __builtin_amdgcn_readlane(c, 0), c1 = __builtin_amdgcn_readlane(c, 16);
-                const int c2 = __builtin_amdgcn_readlane(c, 32), c3 = __builtin_amdgcn_readlane(c, 48);
-                pf_voff0 = (uint32_t)((lane < 32 ? c0 : c1) + 2 * (lane & 31)) * 8u;
-                pf_voff1 = (uint32_t)((lane < 32 ? c2 : c3) + 2 * (lane & 31)) * 8u;
-                pf_next = reinterpret_cast<const float2*>(xref) + (128 + 80 * (s - 2) + 16);
-                __builtin_amdgcn_wave_barrier();
-                pf_issue(0.0f);                                      // the first data symbol's samples: nothing to hide behind yet, and
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no stores behind them that the loop's counted wait could count on
-            }
-        }
+        if (special && (!COMB || nbu_all <= 2) && lines_ok) pf = pf_setup(has_data, s);        // wave-uniform
         typedef std::true_type with_p;
         if (pf && nbu_all == 1)           for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, no_x{}, with_p{}, s);
         else if (pf && nbu_all == 2)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, no_x{}, with_p{}, s);
