@@ -210,7 +210,36 @@ def ber_vs_tx(torch, idx_t, frames_np, tx, n_bpsc, capi):
             "what": "hard decisions (wifirx_out.idx) vs the transmitter's interleaved coded bits, before decode_mac"}
 
 
-def run_variant(torch, capi, txgen, orc, name, enc, slot_len, n_frames, device, chan_est=0, want_carrier=False,
+class VariantArena:
+    """Device buffers of the variants leg, allocated ONCE for the largest geometry and cut into views per variant (the
+    first version allocated and freed 60-110 GB per variant: 2 s each); plus the TX templates and synthesised batches the
+    variants share (the four config-2 variants run on the same batch)."""
+
+    def __init__(self, torch, n_frames, geometries):
+        self.torch, self.n = torch, n_frames
+        z = lambda nbytes: torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
+        self.iq = z(max(8 * sl for sl, _, _ in geometries) * n_frames)
+        self.idx = z(max(48 * ns for _, ns, _ in geometries) * n_frames)
+        self.llr = z(max(192 * ns * nb for _, ns, nb in geometries) * n_frames)
+        self.car = z(max(384 * ns for _, ns, _ in geometries) * n_frames)
+        self.frames = z(32 * n_frames)
+        self.tx = {}
+        self.synth_key = None
+
+    def views(self, slot_len, n_sym, n_bpsc, want_carrier):
+        t, n = self.torch, self.n
+        iq = self.iq[:n * slot_len * 8].view(t.float32).view(n, slot_len, 2)
+        idx = self.idx[:n * n_sym * 48].view(n, n_sym * 48)
+        llr = self.llr[:n * n_sym * 192 * n_bpsc].view(t.float32).view(n, n_sym * 48 * n_bpsc)
+        car = self.car[:n * n_sym * 384].view(t.float32).view(n, n_sym * 48, 2) if want_carrier else None
+        fr = self.frames.view(n, 32)
+        for b in (idx, llr, car, fr):
+            if b is not None:
+                b.zero_()                   # the kernels only write what a frame fills
+        return iq, fr, idx, llr, car
+
+
+def run_variant(torch, capi, txgen, orc, arena, name, enc, slot_len, n_frames, device, chan_est=0, want_carrier=False,
                 taps=None, snr_db=SNR_DB, cfo_max=CFO_MAX, n_templates=256, seed=4321, cores=1, yardstick=True,
                 parity_frames=4096, cite=""):
     """One more geometry / output set / equaliser through the same timed kernel: device-resident batch made like the
@@ -219,19 +248,22 @@ def run_variant(torch, capi, txgen, orc, name, enc, slot_len, n_frames, device, 
     with the oracle, and -- for a geometry or output set of its own -- this box's memory yardstick."""
     n_sym = txgen.n_sym_for(PSDU_LEN, enc)
     n_bpsc = txgen.RATE_TABLE[enc][0]
-    tx = txgen.encode_psdus(txgen.make_psdus(n_templates, PSDU_LEN, seed=seed), enc)
-    samples = tx.samples
-    if taps is not None:         # multipath on the host templates (tests/golden/sv_taps.npy: one draw per template)
-        samples = txgen.impair(tx.samples, None, cfo=0.0, lead=0, total=tx.samples.shape[1] + taps.shape[1], taps=taps[:n_templates])
+    key = (enc, n_templates, seed, taps is not None)
+    if key not in arena.tx:
+        tx = txgen.encode_psdus(txgen.make_psdus(n_templates, PSDU_LEN, seed=seed), enc)
+        samples = tx.samples
+        if taps is not None:         # multipath on the host templates (tests/golden/sv_taps.npy: one draw per template)
+            samples = txgen.impair(tx.samples, None, cfo=0.0, lead=0, total=tx.samples.shape[1] + taps.shape[1], taps=taps[:n_templates])
+        arena.tx[key] = (tx, samples)
+    tx, samples = arena.tx[key]
     assert LEAD + samples.shape[1] <= slot_len
     rx = capi.WifiRx(bandwidth=BANDWIDTH, frequency=FREQUENCY, sensitivity=0.56, chan_est=chan_est, max_sym=n_sym,
                      llr_bits=n_bpsc, want_carrier=want_carrier, device=device)
-    iq = torch.empty((n_frames, slot_len, 2), dtype=torch.float32, device="cuda")
-    rx.synth_slots(samples, iq.data_ptr(), slot_len, n_frames, LEAD, snr_db, float(cfo_max), seed)
-    frames_t = torch.zeros((n_frames, 32), dtype=torch.uint8, device="cuda")
-    idx_t = torch.zeros((n_frames, n_sym * 48), dtype=torch.uint8, device="cuda")
-    llr_t = torch.zeros((n_frames, n_sym * 48 * n_bpsc), dtype=torch.float32, device="cuda")
-    car_t = torch.zeros((n_frames, n_sym * 48, 2), dtype=torch.float32, device="cuda") if want_carrier else None
+    iq, frames_t, idx_t, llr_t, car_t = arena.views(slot_len, n_sym, n_bpsc, want_carrier)
+    skey = key + (slot_len, snr_db, float(cfo_max))
+    if arena.synth_key != skey:      # (the box yardstick only reads the samples: a batch stays valid for the next variant on it)
+        rx.synth_slots(samples, iq.data_ptr(), slot_len, n_frames, LEAD, snr_db, float(cfo_max), seed)
+        arena.synth_key = skey
     torch.cuda.synchronize()
     out = capi.Out(frames_t.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), car_t.data_ptr() if want_carrier else None,
                    None, 0, 1, None)
@@ -252,7 +284,7 @@ def run_variant(torch, capi, txgen, orc, name, enc, slot_len, n_frames, device, 
            "gsamples_per_s": float(n_frames) * slot_len / (kernel_ms * 1e-3) / 1e9,
            "algorithmic_bytes_per_frame": bpf, "frac": bpf * n_frames / (kernel_ms * 1e-3) / HBM_PEAK,
            "frames_complete": int(((fr["flags"] & capi.F_COMPLETE) != 0).sum())}
-    res["ber_vs_tx"] = ber_vs_tx(torch, idx_t.view(n_frames, n_sym * 48), fr, tx, n_bpsc, capi)
+    res["ber_vs_tx"] = ber_vs_tx(torch, idx_t, fr, tx, n_bpsc, capi)
     if orc is not None and parity_frames > 0:
         n_p = min(parity_frames, n_frames)
         prm = orc.make_params(bandwidth=BANDWIDTH, frequency=FREQUENCY, max_sym=n_sym, llr_bits=n_bpsc, chan_est=chan_est)
@@ -265,15 +297,12 @@ def run_variant(torch, capi, txgen, orc, name, enc, slot_len, n_frames, device, 
         res["parity"] = {"frames_checked": n_p, "mismatching_values": mism}
     if yardstick:
         box = box_yardstick(iq.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), car_t.data_ptr() if want_carrier else None,
-                            n_frames, slot_len, LEAD, n_sym, n_bpsc)
+                            n_frames, slot_len, LEAD, n_sym, n_bpsc, reps=2)
         res["box"] = box
         if box.get("available"):
             res["kernel_vs_box_floor"] = kernel_ms / box["mem_floor_ms"]
     rx.close()
-    del iq, frames_t, idx_t, llr_t, car_t
-    torch.cuda.empty_cache()
     return res
-
 
 
 def collective_info(dist, torch, backend, rank, local_rank, world, coll_dev):
@@ -302,6 +331,7 @@ def collective_info(dist, torch, backend, rank, local_rank, world, coll_dev):
 
 
 def main():
+    t_main = time.perf_counter()
     args = parse_args()
     stub = os.environ.get("WIFIRX_BENCH_STUB") == "1"        # CPU rehearsal of the launcher + all-gather plumbing (tests/)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -800,6 +830,7 @@ def main():
                                        "frac": bpf * n_frames / (ms0 * 1e-3) / HBM_PEAK,
                                        "frames_complete": int(((fr0["flags"] & capi.F_COMPLETE) != 0).sum()),
                                        "note": "config 2 with CFO = 0 (IRS_tranceiver.py:121 range centre), device kernel time"}}
+        t_var = time.perf_counter()
         if not args.no_variants:
             # the other BASELINE.json geometries, the reference's own output set and the other equalisers through the same
             # kernel, each with channel BER and oracle parity of its first 4096 frames; the headline's buffers go first
@@ -808,19 +839,22 @@ def main():
             n_var = args.variant_frames or n_frames
             taps = np.load(os.path.join(ROOT, "tests", "golden", "sv_taps.npy"))
             V = result["variants"]
+            geo = [(sl, txgen.n_sym_for(PSDU_LEN, e), txgen.RATE_TABLE[e][0]) for sl, e in ((1472, 7), (8576, 0), (SLOT_LEN, ENCODING))]
+            arena = VariantArena(torch, n_var, geo)
             kw = dict(n_frames=n_var, device=local_rank, cores=cores)
-            V["config3_geometry"] = run_variant(torch, capi, txgen, orc, "BASELINE.json configs[2] geometry: 64-QAM 3/4, slot 1472, "
+            V["config3_geometry"] = run_variant(torch, capi, txgen, orc, arena, "BASELINE.json configs[2] geometry: 64-QAM 3/4, slot 1472, "
                                                 "multipath taps tests/golden/sv_taps.npy (utils/SV_channel.py:81-86,128 draws), "
                                                 "LS, 20 dB", 7, 1472, taps=taps, cite="gnu_radio/IRS_AP.py:81,268-285", **kw)
-            V["config1_geometry"] = run_variant(torch, capi, txgen, orc, "BASELINE.json configs[0] geometry: BPSK 1/2, slot 8576, "
+            V["config1_geometry"] = run_variant(torch, capi, txgen, orc, arena, "BASELINE.json configs[0] geometry: BPSK 1/2, slot 8576, "
                                                 "AWGN 20 dB", 0, 8576, cite="gnu_radio/IRS_AP.py:268-285", **kw)
-            V["carrier_on"] = run_variant(torch, capi, txgen, orc, "config 2 with the reference's own output set: equalised points "
+            V["carrier_on"] = run_variant(torch, capi, txgen, orc, arena, "config 2 with the reference's own output set: equalised points "
                                           "on `carrier` (want_carrier = 1), LS", ENCODING, SLOT_LEN, want_carrier=True,
                                           cite="gnu_radio/IRS_AP.py:293,312-313", **kw)
             for ce, nm in ((1, "lms"), (2, "comb"), (3, "sta")):
-                V[nm] = run_variant(torch, capi, txgen, orc, "config 2 with the %s equaliser" % nm.upper(), ENCODING, SLOT_LEN,
+                V[nm] = run_variant(torch, capi, txgen, orc, arena, "config 2 with the %s equaliser" % nm.upper(), ENCODING, SLOT_LEN,
                                     chan_est=ce, yardstick=False, cite="gnu_radio/IRS_AP.py:139-141", **kw)
                 V[nm]["vs_LS_same_run"] = V[nm]["kernel_ms"] / kernel_ms_avg
+        result["wall_s"] = {"whole_process": time.perf_counter() - t_main, "variants_leg": time.perf_counter() - t_var}
 
     if rank == 0:
         print(json.dumps(result))
