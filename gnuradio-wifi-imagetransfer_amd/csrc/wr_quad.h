@@ -52,14 +52,6 @@ namespace wr {
 #define WR_DMA_PREFETCH 1        // BPSK / QPSK loops of the usual output set: the next symbol's samples by LDS-DMA (global_load_lds_dwordx4), requested while this symbol is computed
 #endif
 #define WR_QLDS_PFX (WR_DMA_PREFETCH ? 256 : 0)       // floats behind the LLR-weight area that complete the 2-kB prefetch buffer (4 frames x 64 samples x 8 B)
-#ifndef WR_X_COLD
-#define WR_X_COLD 0              // the loops of the other output sets are marked unlikely: the register allocator spills there, not in the timed loops
-#endif
-#if WR_X_COLD
-#define WR_UNLIKELY(c) __builtin_expect(!!(c), 0)
-#else
-#define WR_UNLIKELY(c) (c)
-#endif
 #ifndef WR_X_LOOPS
 #define WR_X_LOOPS 1             // constellation loops with whole-line stores for the other output sets too (carrier, weights, moments, planes alone)
 #endif
@@ -1745,11 +1737,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #endif
         else
 #endif
-        if (WR_UNLIKELY(special_x && nbu_all == 1))      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, no_p{}, s);
-        else if (WR_UNLIKELY(special_x && nbu_all == 2)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, no_p{}, s);
+        if (special_x && nbu_all == 1)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, no_p{}, s);
+        else if (special_x && nbu_all == 2) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, no_p{}, s);
 #if WR_NB_LOOPS > 1
-        else if (WR_UNLIKELY(!COMB && special_x && nbu_all == 4)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, no_p{}, s);
-        else if (WR_UNLIKELY(!COMB && special_x && nbu_all == 6)) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, no_p{}, s);
+        else if (!COMB && special_x && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, no_p{}, s);
+        else if (!COMB && special_x && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, no_p{}, s);
 #endif
         else                              for (; more; s++) more = symbol(std::true_type{}, nb_any{}, no_x{}, no_p{}, s);
       } else
