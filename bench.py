@@ -337,6 +337,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
 
+    # stdout carries ONE JSON line and nothing else: whatever the libraries print there while this runs (RCCL's version banner,
+    # gloo's connection notes) is sent to stderr, at the file-descriptor level; the descriptor comes back for the JSON line
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -382,6 +388,8 @@ def main():
     want_pdus = do_decode or args.pdu_steps > 0
 
     if stub:
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         run_stub(args, rank, world, dist, wdist, torch)
         return
 
@@ -856,12 +864,14 @@ def main():
                 V[nm]["vs_LS_same_run"] = V[nm]["kernel_ms"] / kernel_ms_avg
         result["wall_s"] = {"whole_process": time.perf_counter() - t_main, "variants_leg": time.perf_counter() - t_var}
 
-    if rank == 0:
-        print(json.dumps(result))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     rx.close()
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 def run_stub(args, rank, world, dist, wdist, torch):
