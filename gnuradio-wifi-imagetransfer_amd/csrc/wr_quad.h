@@ -52,6 +52,9 @@ namespace wr {
 #define WR_DMA_PREFETCH 1        // BPSK / QPSK loops of the usual output set: the next symbol's samples by LDS-DMA (global_load_lds_dwordx4), requested while this symbol is computed
 #endif
 #define WR_QLDS_PFX (WR_DMA_PREFETCH ? 256 : 0)       // floats behind the LLR-weight area that complete the 2-kB prefetch buffer (4 frames x 64 samples x 8 B)
+#ifndef WR_LTS_SKIP_IDLE
+#define WR_LTS_SKIP_IDLE 1       // LTS candidate rounds 3..7 run for the frame of a pair that needs them only (was: both frames of the pair)
+#endif
 #ifndef WR_X_LOOPS
 #define WR_X_LOOPS 1             // constellation loops with whole-line stores for the other output sets too (carrier, weights, moments, planes alone)
 #endif
@@ -414,9 +417,10 @@ __device__ __forceinline__ void lts_candidates2(const int (&cq0)[10], const int 
 #pragma unroll
         for (int e = 0; e < 2; e++) cand[e][r] = 0;
         if (!(need[0] || need[1])) continue;
-        int best[2];
+        int best[2] = { 0, 0 };
 #pragma unroll
-        for (int e = 0; e < 2; e++) {                           // no branch in here: a frame that needs no further round just idles along
+        for (int e = 0; e < 2; e++) {                           // rounds 0..2: no branch in here (both frames run them); the candidate rounds
+            if (WR_LTS_SKIP_IDLE && r > 2 && !need[e]) continue; // behind them only for the frame that needs them (wave-uniform)
             int m = km[e][0];
 #pragma unroll
             for (int n = 1; n < 10; n++) m = km[e][n] > m ? km[e][n] : m;
@@ -433,9 +437,10 @@ __device__ __forceinline__ void lts_candidates2(const int (&cq0)[10], const int 
             }
             if (!(need[0] || need[1])) continue;
         }
-        int w[2];
+        int w[2] = { 0, 0 };
 #pragma unroll
         for (int e = 0; e < 2; e++) {
+            if (WR_LTS_SKIP_IDLE && r >= 2 && !need[e]) continue;
             int wl = 0x7fffffff;
 #pragma unroll
             for (int n = 0; n < 10; n++) {

@@ -42,10 +42,18 @@ def main():
     ap.add_argument("--planes-only", action="store_true", help="bit planes + records alone (what the stream path asks for)")
     ap.add_argument("--csi", action="store_true", help="LLRs weighted by |H|^2 (WIFIRX_P_LLR_CSI)")
     ap.add_argument("--stats", action="store_true", help="the probe's moments (sym_stats)")
+    ap.add_argument("--sv", action="store_true", help="multipath on the templates (tests/golden/sv_taps.npy: bench.py's config3_geometry)")
+    ap.add_argument("--snr", type=float, default=None)
     a = ap.parse_args()
     from wifirx import txgen
     enc, slot, snr = {2: (2, 4608, 20.0), 3: (7, 1472, 30.0), 1: (0, 8576, 20.0)}[a.geometry]
-    tx = txgen.encode_psdus(txgen.make_psdus(64, 294, seed=5), enc)
+    tx = txgen.encode_psdus(txgen.make_psdus(256 if a.sv else 64, 294, seed=5), enc)
+    samples = tx.samples
+    if a.sv:
+        taps = np.load(os.path.join(ROOT, "tests", "golden", "sv_taps.npy"))[:256]
+        samples = txgen.impair(tx.samples, None, cfo=0.0, lead=0, total=tx.samples.shape[1] + taps.shape[1], taps=taps)
+    if a.snr is not None:
+        snr = a.snr
     n_bpsc = txgen.RATE_TABLE[enc][0]
     mods = [load_capi(p, str(i)) for i, p in enumerate(a.libs)]
     rxs = [m.WifiRx(max_sym=tx.n_sym, llr_bits=n_bpsc, chan_est=a.eq, want_carrier=a.carrier) for m in mods]
@@ -55,7 +63,7 @@ def main():
     m0, rx0 = mods[0], rxs[0]
     n = a.frames
     iq = rx0.alloc(n * slot * 8)
-    rx0.synth_slots(tx.samples, iq.ptr, slot, n, 160, snr, 0.037, 99)
+    rx0.synth_slots(samples, iq.ptr, slot, n, 160, snr, 0.037, 99)
     planes = a.planes or a.planes_only
     dev = rx0.alloc_out(n, want_hbits=planes, want_stats=a.stats)
     rx0.sync()
