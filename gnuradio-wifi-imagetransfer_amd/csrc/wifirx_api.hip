@@ -132,12 +132,21 @@ int fail(wifirx_handle* h, int code, const std::string& msg)
             return fail(h, WIFIRX_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
+// A failed allocation: HIP keeps the last non-success code until it is read (hipGetLastError), and the launch wrappers of
+// wr_kernels.hip / wr_decode.hip end in `return hipGetLastError()` -- a later launch that went fine would report this allocation's
+// hipErrorOutOfMemory.  Every ENOMEM path reads it away.
+int oom(wifirx_handle* h, const char* what, hipError_t e)
+{
+    (void)hipGetLastError();
+    return fail(h, WIFIRX_ENOMEM, std::string(what) + ": " + hipGetErrorString(e));
+}
+
 int ensure(wifirx_handle* h, void** p, size_t* have, size_t need)
 {
     if (*have >= need) return WIFIRX_OK;
     if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
     hipError_t e = hipMalloc(p, need);
-    if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return oom(h, "hipMalloc", e);
     *have = need;
     return WIFIRX_OK;
 }
@@ -148,7 +157,7 @@ int ensure_pinned(wifirx_handle* h, void** p, size_t* have, size_t need)
     if (*p) { (void)hipHostFree(*p); *p = nullptr; *have = 0; }
     need += need / 2;
     hipError_t e = hipHostMalloc(p, need, hipHostMallocDefault);
-    if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return oom(h, "hipHostMalloc", e);
     *have = need;
     return WIFIRX_OK;
 }
@@ -304,7 +313,7 @@ int wifirx_dev_alloc(wifirx_handle* h, size_t bytes, void** out)
     if (!h || !out) return WIFIRX_EINVAL;
     HIP_TRY(h, hipSetDevice(h->device));
     hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return oom(h, "hipMalloc", e);
     return WIFIRX_OK;
 }
 
@@ -506,7 +515,7 @@ int wifirx_synth_slots(wifirx_handle* h, const float* templates, int templates_o
     if (!templates_on_device) {
         size_t bytes = (size_t)n_templates * frame_len * sizeof(float2);
         hipError_t e = hipMalloc(&tmp, bytes);
-        if (e != hipSuccess) return fail(h, WIFIRX_ENOMEM, "hipMalloc(templates)");
+        if (e != hipSuccess) return oom(h, "hipMalloc(templates)", e);
         e = hipMemcpyAsync(tmp, templates, bytes, hipMemcpyHostToDevice, h->stream);
         if (e != hipSuccess) {
             (void)hipFree(tmp);

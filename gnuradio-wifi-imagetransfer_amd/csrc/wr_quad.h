@@ -1235,7 +1235,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         // two instructions of 1 kB: lanes 0..31 -> 64 samples of frame 0 (2), lanes 32..63 -> frame 1 (3); LDS address = M0 + 16 lane
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
                      "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4"
-                     :: "s"(pf_m0), "s"(pf_m1), "v"(pf_voff0), "v"(pf_voff1), "s"(pf_next), "v"(dep) : "memory");
+                     :: "s"(pf_m0), "s"(pf_m1), "v"(pf_voff0), "v"(pf_voff1), "s"(pf_next), "v"(dep) : "memory", "m0");
         pf_next += 80;
     };
     // Can the data loop that begins at symbol s0 take the prefetch?  Every row with data symbols must end at the same symbol and

@@ -78,6 +78,7 @@ class wifi_phy_rx(grshim.sync_block):
         self.raise_on_error = True
         self.push_errors = 0
         self.last_error = ""
+        self.stream_dead = False        # the library has declared the stream dead (WIFIRX_EDEAD): work() ends the block
 
     # ---- setters generated for the hier block's parameters (gnu_radio/IRS_user.py:229,265,273;
     #      equaliser setters at gnu_radio/IRS_AP.py:348,373,382) ----
@@ -136,6 +137,15 @@ class wifi_phy_rx(grshim.sync_block):
                 # block's would; otherwise it is counted and work() reports the consumed items.
                 self.push_errors += 1
                 self.last_error = capi.lib().wifirx_last_error(self._h).decode()
+                if rc == capi.EDEAD:
+                    # the stream is gone for good (include/wifirx.h: ERRORS): returning "0 items consumed" would have the
+                    # scheduler hand the same items in for ever.  Publish what is finished, then end the block -- by the
+                    # exception with raise_on_error, by WORK_DONE (-1) without.
+                    self.stream_dead = True
+                    self._publish()
+                    if self.raise_on_error:
+                        self._rx._check(rc)
+                    return -1
                 if self.raise_on_error:
                     self._rx._check(rc)
                 n = self._rx.push_consumed()
@@ -150,11 +160,15 @@ class wifi_phy_rx(grshim.sync_block):
         rc = 0
         try:
             for _ in range(3):
+                if self.stream_dead:                 # no flush can succeed any more (work() has reported it)
+                    break
                 rc = self._push(self._h, None, 0, 0)
                 if rc == 0:
                     break
                 self.push_errors += 1
                 self.last_error = capi.lib().wifirx_last_error(self._h).decode()
+                if rc == capi.EDEAD:
+                    self.stream_dead = True
         finally:
             self._publish()
         if rc and self.raise_on_error:

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("WIFIRX_LIB") or os.path.join(_HERE, "libwifirx.so")  
 ABI_VERSION = 4
 DECODE_INPUT = "planes"      # what demod_batch(decode=True) hands decode_mac: "planes" (wifirx_out.hbits) or "idx"
 EQ_LS, EQ_LMS, EQ_COMB, EQ_STA = 0, 1, 2, 3
+OK, EINVAL, ENODEV, ENOMEM, EHIP, ERANGE, EDEAD = 0, -1, -2, -3, -4, -5, -6      # WIFIRX_E*; EDEAD: the stream is dead, do not retry
 STREAM_BATCH_MAX = 1 << 27          # WIFIRX_STREAM_BATCH_MAX
 P_BANDWIDTH, P_FREQUENCY, P_SENSITIVITY, P_CHAN_EST, P_STREAM_BATCH, P_DECODE_SMALL_MAX, P_LLR_CSI, P_STREAM_IDX = 1, 2, 3, 4, 5, 6, 7, 8
 F_DETECTED, F_SYNC, F_SIGNAL, F_COMPLETE, F_LLR, F_DECODED, F_CRC_OK = 1, 2, 4, 8, 16, 32, 64

@@ -121,6 +121,8 @@ def run_stream(block, samples: np.ndarray, chunk: int = 8192, finish: bool = Tru
     pos = stalls = 0
     while pos < samples.size:
         n = block.work([samples[pos:pos + chunk]], [])
+        if n == -1:                     # WORK_DONE: the block has ended the flowgraph (a dead stream, wifirx/block.py)
+            break
         if n <= 0:                      # nothing consumed: the scheduler calls again; give up after a few in a row
             stalls += 1
             if stalls > 8:

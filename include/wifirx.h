@@ -39,6 +39,7 @@ extern "C" {
 #define WIFIRX_ENOMEM   -3   /* device or host allocation failed */
 #define WIFIRX_EHIP     -4   /* HIP runtime error (wifirx_last_error() has the text) */
 #define WIFIRX_ERANGE   -5   /* buffer too small / index out of range */
+#define WIFIRX_EDEAD    -6   /* the handle's stream is dead (its sample buffer was lost): nothing to retry, destroy the handle */
 
 /* Equalizer enum of the reference: ieee802_11.Equalizer (gnu_radio/IRS_AP.py:139-141). */
 #define WIFIRX_EQ_LS   0
@@ -126,8 +127,9 @@ typedef struct wifirx_config {
  * (once, before it takes anything); the failed batch stays staged in the library and the call after that runs it
  * again before going on.  A pass whose frames are queued is committed: a device failure behind that point (the carry of the
  * samples a pending frame still needs) is never reported as a failed push.  If it struck before the sample buffer was
- * touched, the stream goes on unharmed; if the buffer can no longer be trusted, every later push returns WIFIRX_EHIP
- * with wifirx_push_consumed() = 0 and a text that says the stream is dead -- not a condition to retry: destroy the handle. */
+ * touched, the stream goes on unharmed; if the buffer can no longer be trusted, every later push returns WIFIRX_EDEAD
+ * with wifirx_push_consumed() = 0 and a text that says the stream is dead -- not a condition to retry: destroy the handle
+ * (a GNU Radio work() answers it with WORK_DONE, wifirx/block.py). */
 #define WIFIRX_P_STREAM_BATCH 5
 #define WIFIRX_STREAM_BATCH_MAX (1u << 27)
 /* decode_mac has two kernels with identical results: 128 frames per wave (throughput; a lone wave needs ~4 ms)

@@ -389,7 +389,7 @@ def test_failure_behind_the_commit_of_a_pass_doubles_nothing(monkeypatch, batch)
             else:
                 rx.push(x[p:p + chunk])
         except capi.WifiRxError as e:
-            assert e.code == -4 and "lost" in str(e), str(e)
+            assert e.code == capi.EDEAD and "lost" in str(e), str(e)
             assert rx.push_consumed() == 0
             dead_at = p if p is not None else x.size
             break
@@ -401,6 +401,40 @@ def test_failure_behind_the_commit_of_a_pass_doubles_nothing(monkeypatch, batch)
     rx.close()
     frames = np.concatenate([g["frames"] for g in got])
     assert len(frames) >= 1 and np.array_equal(frames, ref_frames[:len(frames)])
+
+
+def test_block_ends_on_a_dead_stream(monkeypatch):
+    """a dead stream answers every push with WIFIRX_EDEAD and 0 consumed samples.  work() used to count the error and
+    return 0 items with raise_on_error off -- the scheduler hands the same items in again, for ever.  Now it publishes what is
+    finished and returns WORK_DONE (-1) -- or raises, with raise_on_error --, and stop() makes no flush that cannot succeed."""
+    from wifirx import block, capi, grshim
+    x, psdus = build_stream(seed=5)
+    for raise_on_error in (False, True):
+        monkeypatch.setenv("WIFIRX_TEST_FAIL_CARRY", "-2")
+        blk = block.wifi_phy_rx(bandwidth=20e6, publish_carrier=False, batch_samples=0)
+        blk.raise_on_error = raise_on_error
+        got = []
+        grshim.msg_connect(blk, "mac_out", grshim.sink_block(got.append), "in")
+        calls = []
+        work = blk.work
+        blk.work = lambda i, o: (calls.append(1), work(i, o))[1]
+        if raise_on_error:
+            with pytest.raises(capi.WifiRxError) as ei:
+                grshim.run_stream(blk, x, chunk=4096, finish=False)
+            assert ei.value.code == capi.EDEAD
+        else:
+            pos = grshim.run_stream(blk, x, chunk=4096, finish=False)
+            assert pos < x.size
+        assert blk.stream_dead and "lost" in blk.last_error
+        n_calls, n_err = len(calls), blk.push_errors
+        assert n_err == 1                            # one failed push, not a spin of them
+        assert blk.work([x[:4096]], []) == -1 if not raise_on_error else True
+        blk.stop()                                   # no flush attempts on a dead stream
+        assert blk.push_errors <= n_err + 1
+        assert 1 <= len(got) <= len(psdus)           # what was finished before the failure was published
+        for (meta, blob), want in zip(got, psdus):
+            assert np.array_equal(np.asarray(blob), want[:-4])
+        blk.close()
 
 
 def test_block_stop_flushes_and_publishes_through_a_pending_worker_error(monkeypatch):

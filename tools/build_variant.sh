@@ -10,6 +10,6 @@ cp -r $ROOT/gnuradio-wifi-imagetransfer_amd/csrc $T/gnuradio-wifi-imagetransfer_
 cp -r $ROOT/include $T/
 cd $T/gnuradio-wifi-imagetransfer_amd/csrc
 make clean -s
-make -j4 -s FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fPIC -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -I../../include -I. -Wall -Wno-unused-function $*"
+make -j4 -s FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fPIC -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize -I../../include -I. -Wall -Wno-unused-function -Wno-inline-asm $*"
 cp ../wifirx/libwifirx.so "$OUT"
 rm -rf $T
