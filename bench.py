@@ -398,7 +398,7 @@ def main():
     n_bpsc = txgen.RATE_TABLE[ENCODING][0]
 
     # ---- synthetic input: host templates -> device slots (Philox AWGN + CFO on the GPU) ----
-    psdu = txgen.make_psdus(N_TEMPLATES, PSDU_LEN, seed=2025 + rank)
+    psdu = txgen.make_psdus(N_TEMPLATES, PSDU_LEN, seed=rank_seeds(rank)["payload_seed"])
     tx = txgen.encode_psdus(psdu, ENCODING)
     frame_len = tx.samples.shape[1]
     assert LEAD + frame_len <= SLOT_LEN
@@ -407,7 +407,7 @@ def main():
                      llr_bits=n_bpsc, want_carrier=False, device=local_rank)
     iq = torch.empty((n_frames, SLOT_LEN, 2), dtype=torch.float32, device="cuda")
     cfo = torch.empty(n_frames, dtype=torch.float32, device="cuda")
-    synth_seed = 1234 + 7919 * rank
+    synth_seed = rank_seeds(rank)["synth_seed"]
     rx.synth_slots(tx.samples, iq.data_ptr(), SLOT_LEN, n_frames, LEAD, SNR_DB, float(CFO_MAX), synth_seed, cfo.data_ptr())
     # outputs as torch tensors (device memory + RCCL plumbing only)
     frames_t = torch.zeros((n_frames, 32), dtype=torch.uint8, device="cuda")
@@ -500,7 +500,8 @@ def main():
     value = total_samples / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     kernel_ms_avg = kernel_ms / args.steps
-    per_rank = [{"rank": rank, "kernel_ms": kernel_ms_avg, "gsamples_per_s": float(n_frames) * SLOT_LEN * args.steps / t_own / 1e9}]
+    per_rank = [dict({"rank": rank, "kernel_ms": kernel_ms_avg, "gsamples_per_s": float(n_frames) * SLOT_LEN * args.steps / t_own / 1e9},
+                     **rank_seeds(rank))]
     if use_dist:
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
@@ -893,6 +894,11 @@ def main():
     rx.close()
 
 
+def rank_seeds(rank):
+    """Every rank draws its own payloads and its own noise / CFO realisations (weak scaling: 1 M distinct frames per GPU)."""
+    return {"payload_seed": 2025 + rank, "synth_seed": 1234 + 7919 * rank}
+
+
 def run_stub(args, rank, world, dist, wdist, torch):
     """CPU rehearsal (WIFIRX_BENCH_STUB=1, gloo): the launcher, the rank bookkeeping, the barrier / max-over-ranks timing
     and the chunked PDU all-gather with a stand-in for the compute step.  The JSON line says so; nothing here is a
@@ -943,8 +949,14 @@ def run_stub(args, rank, world, dist, wdist, torch):
         flags = [None] * world
         dist.all_gather_object(flags, bool(ok))
         ok = all(flags)
+    per_rank = [dict({"rank": rank, "pid": os.getpid()}, **rank_seeds(rank))]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
     if rank == 0:
         print(json.dumps({"metric": "STUB (no GPU work): launcher + all-gather rehearsal", "value": 0.0, "unit": "samples/s",
+                          "per_rank": per_rank, "gathered_bytes_per_rank": (PSDU_STRIDE + 32) * n_frames * world,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
                           "config": {"workload": "stub", "parallelism": "gloo, %d ranks" % world},

@@ -251,9 +251,15 @@ void demod_batch_kernel(const float2* __restrict__ iq, uint32_t slot_len, uint32
     PreSamples ps[4];
 #pragma unroll
     for (int f = 0; f < 4; f++) preamble_load(pf[f], lane, ps[f]);
+    // exp(-j float(cfo_c 64)) of the four frames in one pass: row f of the wave works on frame f
+    c32 w64r;
+    {
+        const int row = lane >> 4;
+        w64r = preamble_w64_rows(row == 0 ? pf[0].cfo_c : row == 1 ? pf[1].cfo_c : row == 2 ? pf[2].cfo_c : pf[3].cfo_c);
+    }
 #pragma unroll
     for (int p = 0; p < 2; p++) {
-        preamble_derotate_pair(pf[2 * p], pf[2 * p + 1], ps[2 * p], ps[2 * p + 1], lds[wave], lane);
+        preamble_derotate_pair(pf[2 * p], pf[2 * p + 1], ps[2 * p], ps[2 * p + 1], bcast(w64r, 32 * p), bcast(w64r, 32 * p + 16), lds[wave], lane);
         __builtin_amdgcn_wave_barrier();
         preamble_pair_finish(pf[2 * p], pf[2 * p + 1], p, lds[wave], lane, seed);
         __builtin_amdgcn_wave_barrier();
@@ -295,9 +301,14 @@ void demod_stream_kernel(const float2* __restrict__ x, long n_samp, const Stream
         }
         preamble_load(pf[f], lane, ps[f]);
     }
+    c32 w64r;
+    {
+        const int row = lane >> 4;
+        w64r = preamble_w64_rows(row == 0 ? pf[0].cfo_c : row == 1 ? pf[1].cfo_c : row == 2 ? pf[2].cfo_c : pf[3].cfo_c);
+    }
 #pragma unroll
     for (int p = 0; p < 2; p++) {
-        preamble_derotate_pair(pf[2 * p], pf[2 * p + 1], ps[2 * p], ps[2 * p + 1], lds[wave], lane);
+        preamble_derotate_pair(pf[2 * p], pf[2 * p + 1], ps[2 * p], ps[2 * p + 1], bcast(w64r, 32 * p), bcast(w64r, 32 * p + 16), lds[wave], lane);
         __builtin_amdgcn_wave_barrier();
         preamble_pair_finish(pf[2 * p], pf[2 * p + 1], p, lds[wave], lane, seed);
         __builtin_amdgcn_wave_barrier();

@@ -269,6 +269,14 @@ struct PreSamples { c32 xs[6]; };
 __device__ __forceinline__ void preamble_load(const PreFrame& f, int lane, PreSamples& ps)
 {
     const long ns = f.search ? f.n_samp : 0;
+    if (f.search && f.t >= 16 && f.t + 368 <= f.n_samp) {
+        // (wave-uniform; the usual case) all 384 samples lie inside the slot / stream buffer: one pointer, six loads at constant
+        // offsets -- the per-sample range tests of load_sample() are 64-bit compares and a branch around every load
+        const float2* p = f.x + (f.t - 16) + lane;
+#pragma unroll
+        for (int pass = 0; pass < 6; pass++) { const float2 v = p[64 * pass]; ps.xs[pass] = { v.x, v.y }; }
+        return;
+    }
 #pragma unroll
     for (int pass = 0; pass < 6; pass++) ps.xs[pass] = load_sample(f.x, f.t - 16 + (pass * 64 + lane), ns);
 }
@@ -293,8 +301,17 @@ __device__ __forceinline__ int quant8(float x, float scale)
     return q < -127 ? -127 : q;
 }
 
+// w64_0 / w64_1: exp(-j float(cfo_c 64)) of the two frames (spec rule 5a), formed by the caller for all frames of the wave in ONE
+// pass of the sine / cosine (row f of the wave computes frame f's; the values are wave-uniform here).
+__device__ __forceinline__ c32 preamble_w64_rows(float cfo_c_row)
+{
+    c32 w;
+    sp_sincos(-cfo_c_row * 64.0f, w.im, w.re);
+    return w;
+}
+
 __device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const PreFrame& f1, const PreSamples& s0,
-                                                       const PreSamples& s1, float* ylds, int lane)
+                                                       const PreSamples& s1, c32 w64_0, c32 w64_1, float* ylds, int lane)
 {
     if (!(f0.search || f1.search)) return;                  // wave-uniform
     // Both frames in one piece of straight-line code: their chains (two sincos, the carried phasor, the maximum over the
@@ -308,7 +325,7 @@ __device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const
     for (int e = 0; e < 2; e++) {
         const float cfo = e ? f1.cfo_c : f0.cfo_c;
         sp_sincos(-cfo * (float)lane, wl[e].im, wl[e].re);
-        sp_sincos(-cfo * 64.0f, w64[e].im, w64[e].re);
+        w64[e] = e ? w64_1 : w64_0;
     }
 #pragma unroll
     for (int pass = 0; pass < 6; pass++) {
@@ -346,69 +363,82 @@ __device__ __forceinline__ void preamble_derotate_pair(const PreFrame& f0, const
 }
 
 // Stage 1 of the search: corr_q[i] = sum_k conj(lq[k]) yq[i + k] for the 320 lags of both frames of the pair in exact
-// integer arithmetic, as a GEMM on v_mfma_i32_16x16x64_i8 (operand layout: tools/mfma_i8_probe.hip).  Lags in blocks of
-// 8, i = 8 a + b:
-//   M: 80 rows (frame e, block a) = 5 tiles of 16;   the row of (e, a) is the 144 contiguous bytes from sample 8a on
+// integer arithmetic, as a GEMM on v_mfma_i32_16x16x64_i8 (operand layout: tools/mfma_i8_probe.hip).  Round 5: the TAPS are
+// the row-side operand (WR_LTS_MFMA_A8), the SAMPLES the column side, so that the real and the imaginary sum of a lag land
+// in the same lane -- |corr_q|^2 then needs no exchange, and all 64 lanes hold lags (with the samples on the row side the
+// two sums sat 8 lanes apart and half the lanes idled through the candidate search).  Lags in blocks of 8, i = 8 a + b:
+//   N: 80 columns (frame e, block a) = 5 tiles of 16; the column of (e, a) is the 144 contiguous bytes from sample 8a on
 //      (read as 192: the taps beyond are zero);
-//   N: 16 columns = (b, real part) b = 0..7, then (b, imaginary part);      K: 192 = 3 instructions of 64.
-// Instruction t takes the bytes phi = 64 t + 16 kk + j (kk = lane >> 4, j = 0..15): one ds_read_b128 per lane, tile
-// and t; the matching B bytes come as one 16-byte load from WR_LTS_MFMA_B8.
-// Row r' = 4 q + rho of a tile (q = lane >> 4 of the result lane, rho = result register) stands for block
-//   a_local = 8 (rho >> 1) + 2 q + (rho & 1),
-// tiles 0, 1 = frame 0 blocks 0..31; tile 2 = frame 0 blocks 32..39 (rho 0, 1) and frame 1 blocks 0..7 (rho 2, 3);
-// tiles 3, 4 = frame 1 blocks 8..39 -- so that result register n of a frame (n = 0..9 in that order) holds, on the
-// lanes with (lane & 8) == 0, the lags 64 (n >> 1) + 8 (n & 1) + lane: a frame's lags split by register, never by lane.
+//   M: 16 rows = (b, part): row r' = 4 q + rho <-> b = 2 q + (rho >> 1), part = rho & 1;      K: 192 = 3 instructions of 64.
+// Instruction t takes the bytes phi = 64 t + 16 kk + j (kk = lane >> 4, j = 0..15): one ds_read_b128 per lane, tile and t;
+// the matching tap bytes come as one 16-byte load from WR_LTS_MFMA_A8.
+// Tiles 0, 1 = frame 0 blocks 0..31; tile 2 = frame 0 blocks 32..39 (columns 0..7) and frame 1 blocks 0..7 (columns 8..15);
+// tiles 3, 4 = frame 1 blocks 8..39.  Result register rho of lane (q = lane >> 4, col = lane & 15) of a tile: rho = 0 / 1 the
+// real / imaginary sum of lag 8 a(col) + 2 q, rho = 2 / 3 those of lag 8 a(col) + 2 q + 1.
 __device__ __forceinline__ void lts_corr_pair_q8(const float* ylds, int lane, wr_i4 (&acc)[5])
 {
-    const int rp = lane & 15, kk = lane >> 4;
-    const int al = 8 * ((rp & 3) >> 1) + 2 * (rp >> 2) + (rp & 1);
-    const int e2 = (rp & 3) >> 1;                    // tile 2: which frame this row belongs to
-    const uint8_t* q8 = reinterpret_cast<const uint8_t*>(ylds + WR_PRE_Q8);
-    const uint8_t* arow[5];
-    arow[0] = q8 + 16 * al + 16 * kk;
-    arow[1] = q8 + 16 * (16 + al) + 16 * kk;
-    arow[2] = q8 + (e2 ? WR_PRE_Q8_FRAME + 16 * (al & 7) : 16 * (32 + (al & 7))) + 16 * kk;
-    arow[3] = q8 + WR_PRE_Q8_FRAME + 16 * (8 + al) + 16 * kk;
-    arow[4] = q8 + WR_PRE_Q8_FRAME + 16 * (24 + al) + 16 * kk;
-    const wr_i4* __restrict__ bt = reinterpret_cast<const wr_i4*>(WR_LTS_MFMA_B8) + lane;
+    const int col = lane & 15, kk = lane >> 4;
+    const uint8_t* q8 = reinterpret_cast<const uint8_t*>(ylds + WR_PRE_Q8) + 16 * kk;
+    const uint8_t* q8b = q8 + WR_PRE_Q8_FRAME;
+    const uint8_t* bcol[5];
+    bcol[0] = q8 + 16 * col;
+    bcol[1] = q8 + 16 * (16 + col);
+    bcol[2] = col < 8 ? q8 + 16 * (32 + col) : q8b + 16 * (col - 8);
+    bcol[3] = q8b + 16 * (8 + col);
+    bcol[4] = q8b + 16 * (24 + col);
+    const wr_i4* __restrict__ at = reinterpret_cast<const wr_i4*>(WR_LTS_MFMA_A8) + lane;
 #pragma unroll
     for (int t = 0; t < 5; t++) acc[t] = wr_i4{ 0, 0, 0, 0 };
 #pragma unroll
     for (int t3 = 0; t3 < 3; t3++) {
-        const wr_i4 bq = bt[64 * t3];
+        const wr_i4 aq = at[64 * t3];
 #pragma unroll
         for (int t = 0; t < 5; t++) {
-            const wr_i4 aq = *reinterpret_cast<const wr_i4*>(arow[t] + 64 * t3);
+            const wr_i4 bq = *reinterpret_cast<const wr_i4*>(bcol[t] + 64 * t3);
             acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aq, bq, acc[t], 0, 0, 0);
         }
     }
 }
 
-// Stage 1 for one frame: the candidate lags.  cq[n] = result register n of the frame (real parts on the lanes with
-// (lane & 8) == 0, imaginary parts eight lanes further up).  The integers are below 2^24, so their float32 images are
-// exact and |corr_q|^2 = fma(im, im, re re) is the same number on the CPU; it is >= +0 and no NaN, so its bit pattern
-// orders like a signed integer; already-taken entries and the lanes that hold imaginary parts are -1.  Per round: one
-// integer max over the wave, then the lowest lag that holds it (per register the first lane of a ballot; lag = base +
-// lane).  The two largest when they are exactly 64 lags apart and the third largest value is below 7/8 of the second
-// (spec rule 6: no rounding of the integer stage can then have changed the leaders); otherwise the eight largest; n_cand =
-// their number.
-__device__ __forceinline__ void lts_candidates2(const int (&cq0)[10], const int (&cq1)[10], const bool (&run)[2], int lane,
+// Stage 1 for both frames of a pair: the candidate lags.  Lane (q, col) holds six slots per frame, slot s = 2 T + h of the
+// frame's tile T = 0..2 (h = rho >> 1): lag = L + 128 (s >> 1) + (s & 1) with L = 8 col + 2 q - 64 e; of the shared tile the
+// half that belongs to the other frame is -1 (frame 0: slots 4, 5 of the columns 8..15; frame 1: slots 0, 1 of the columns
+// 0..7).  The integers are below 2^24, so their float32 images are exact and |corr_q|^2 = fma(im, im, re re) is the same number
+// on the CPU; it is >= +0 and no NaN, so its bit pattern orders like a signed integer; already-taken entries are -1.  Per round:
+// the lane maximum, one integer max over the wave, the lane that holds it (a ballot), that lane's six values through the scalar
+// unit (the first slot that matches: the lowest lag inside a lane), one v_writelane to strike it out.  Several lanes with the
+// maximum (rare): the lowest lag among all entries that hold it, by a minimum over the wave.  The two largest when they are
+// exactly 64 lags apart and the third largest value is below 7/8 of the second (spec rule 6: no rounding of the integer stage can
+// then have changed the leaders); otherwise the eight largest; n_cand = their number.
+// v with lane `lane_s` (wave-uniform) set to -1 (one scalar register per VOP3 on gfx9: the value is the inline constant)
+__device__ __forceinline__ int strike_lane(int v, int lane_s)
+{
+    asm("v_writelane_b32 %0, -1, %1" : "+v"(v) : "s"(lane_s));
+    return v;
+}
+
+__device__ __forceinline__ int lts_mag_key(int re, int im)
+{
+    const float fr = (float)re, fi = (float)im;
+    return (int)__float_as_uint(fma_(fi, fi, fr * fr));
+}
+
+__device__ __forceinline__ void lts_candidates2(const wr_i4 (&acc)[5], const bool (&run)[2], int lane,
                                                 int (&cand)[2][8], int (&n_cand)[2])
 {
-    // both frames of the pair round by round: their reductions are independent chains the scheduler interleaves
-    int km[2][10];
-    const bool holds_re = (lane & 8) == 0;
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-#pragma unroll
-        for (int n = 0; n < 10; n++) {
-            const int c = e ? cq1[n] : cq0[n];
-            const int ci = __builtin_bit_cast(int, dpp_zero<0x108>(__builtin_bit_cast(float, c)));      // row_shl:8: the imaginary part from lane + 8
-            const float fr = (float)c, fi = (float)ci;
-            const float mag = fma_(fi, fi, fr * fr);
-            km[e][n] = holds_re ? (int)__float_as_uint(mag) : -1;
-        }
+    const int col = lane & 15;
+    const bool lo = col < 8;
+    int K[2][6];
+    {
+        const int s0 = lts_mag_key(acc[2][0], acc[2][1]), s1 = lts_mag_key(acc[2][2], acc[2][3]);
+        K[0][0] = lts_mag_key(acc[0][0], acc[0][1]); K[0][1] = lts_mag_key(acc[0][2], acc[0][3]);
+        K[0][2] = lts_mag_key(acc[1][0], acc[1][1]); K[0][3] = lts_mag_key(acc[1][2], acc[1][3]);
+        K[0][4] = lo ? s0 : -1;                      K[0][5] = lo ? s1 : -1;
+        K[1][0] = lo ? -1 : s0;                      K[1][1] = lo ? -1 : s1;
+        K[1][2] = lts_mag_key(acc[3][0], acc[3][1]); K[1][3] = lts_mag_key(acc[3][2], acc[3][3]);
+        K[1][4] = lts_mag_key(acc[4][0], acc[4][1]); K[1][5] = lts_mag_key(acc[4][2], acc[4][3]);
     }
+    const int L0 = 8 * col + 2 * (lane >> 4);
     n_cand[0] = n_cand[1] = 0;
     bool need[2] = { run[0], run[1] };
     int second[2] = { 0, 0 };                                   // the second largest |corr_q|^2 (bit pattern)
@@ -417,13 +447,14 @@ __device__ __forceinline__ void lts_candidates2(const int (&cq0)[10], const int 
 #pragma unroll
         for (int e = 0; e < 2; e++) cand[e][r] = 0;
         if (!(need[0] || need[1])) continue;
-        int best[2] = { 0, 0 };
+        int best[2] = { 0, 0 }, lmax[2] = { 0, 0 };
 #pragma unroll
         for (int e = 0; e < 2; e++) {                           // rounds 0..2: no branch in here (both frames run them); the candidate rounds
             if (WR_LTS_SKIP_IDLE && r > 2 && !need[e]) continue; // behind them only for the frame that needs them (wave-uniform)
-            int m = km[e][0];
+            int m = K[e][0];
 #pragma unroll
-            for (int n = 1; n < 10; n++) m = km[e][n] > m ? km[e][n] : m;
+            for (int n = 1; n < 6; n++) m = K[e][n] > m ? K[e][n] : m;
+            lmax[e] = m;
             best[e] = wave_max_int(m);
             if (r == 1) second[e] = best[e];
         }
@@ -441,19 +472,33 @@ __device__ __forceinline__ void lts_candidates2(const int (&cq0)[10], const int 
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             if (WR_LTS_SKIP_IDLE && r >= 2 && !need[e]) continue;
-            int wl = 0x7fffffff;
+            const int L = L0 - 64 * e;
+            const uint64_t hit = __ballot(lmax[e] == best[e]);
+            if (__builtin_popcountll(hit) == 1) {               // wave-uniform; the usual case
+                const int wl = (int)__builtin_ctzll(hit);
+                int sl = 5;
 #pragma unroll
-            for (int n = 0; n < 10; n++) {
-                const uint64_t hit = __ballot(km[e][n] == best[e]);
-                const int lag = 64 * (n >> 1) + 8 * (n & 1) + (int)__builtin_ctzll(hit | (1ull << 63));
-                const int cl = hit ? lag : 0x7fffffff;
-                wl = cl < wl ? cl : wl;
+                for (int n = 4; n >= 0; n--) sl = __builtin_amdgcn_readlane(K[e][n], wl) == best[e] ? n : sl;
+                w[e] = __builtin_amdgcn_readlane(L, wl) + 128 * (sl >> 1) + (sl & 1);
+                // (a switch over the slot, not a select per slot: one v_writelane is issued, not six)
+                switch (sl) {
+                case 0:  K[e][0] = strike_lane(K[e][0], wl); break;
+                case 1:  K[e][1] = strike_lane(K[e][1], wl); break;
+                case 2:  K[e][2] = strike_lane(K[e][2], wl); break;
+                case 3:  K[e][3] = strike_lane(K[e][3], wl); break;
+                case 4:  K[e][4] = strike_lane(K[e][4], wl); break;
+                default: K[e][5] = strike_lane(K[e][5], wl); break;
+                }
+            } else {
+                int lagl = 0x7fffffff;
+#pragma unroll
+                for (int n = 5; n >= 0; n--) lagl = K[e][n] == best[e] ? L + 128 * (n >> 1) + (n & 1) : lagl;
+                const int wlag = -wave_max_int(-lagl);          // the lowest lag that holds the maximum (a lag names one lane and slot)
+                w[e] = wlag;
+#pragma unroll
+                for (int n = 0; n < 6; n++)
+                    if (L + 128 * (n >> 1) + (n & 1) == wlag) K[e][n] = -1;
             }
-            w[e] = wl;
-            const int wn = ((wl >> 6) << 1) | ((wl >> 3) & 1), wlane = wl & 0x37;
-#pragma unroll
-            for (int n = 0; n < 10; n++)
-                if (n == wn && lane == wlane) km[e][n] = -1;
         }
 #pragma unroll
         for (int e = 0; e < 2; e++)
@@ -639,14 +684,7 @@ __device__ __forceinline__ void preamble_pair_finish(const PreFrame& f0, const P
     if (run[0] || run[1]) {
         wr_i4 acc[5];
         lts_corr_pair_q8(lds, lane, acc);
-        int cq0[10], cq1[10];
-#pragma unroll
-        for (int n = 0; n < 8; n++) cq0[n] = acc[n >> 2][n & 3];
-        cq0[8] = acc[2][0]; cq0[9] = acc[2][1];
-        cq1[0] = acc[2][2]; cq1[1] = acc[2][3];
-#pragma unroll
-        for (int n = 2; n < 10; n++) cq1[n] = acc[3 + ((n - 2) >> 2)][(n - 2) & 3];
-        lts_candidates2(cq0, cq1, run, lane, cand, n_cand);
+        lts_candidates2(acc, run, lane, cand, n_cand);
         int lag;
         ex = lts_exact_pair(lds, lane, cand[0], cand[1], lag);
         lts_top4_pair(ex, lag, lane, n_cand, top_off, top_val);

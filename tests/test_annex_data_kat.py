@@ -192,25 +192,32 @@ def _int_table(name):
 
 
 def test_integer_lts_tables_match_the_lts():
-    """spec rule 6, stage 1: WR_LTS_Q8 = rint(64 l), and WR_LTS_MFMA_B8 (kernels only) against it through the layout of
-    v_mfma_i32_16x16x64_i8 written out independently of tools/gen_tables.py: byte j of entry [t][lane] multiplies byte
-    phi = 64 t + 16 (lane >> 4) + j of a row, k = (phi >> 1) - (col & 7), zero outside the 64 taps"""
+    """spec rule 6, stage 1: WR_LTS_Q8 = rint(64 l), and WR_LTS_MFMA_A8 (kernels only: the taps as the row-side operand of
+    v_mfma_i32_16x16x64_i8) against it through the instruction's layout written out independently of tools/gen_tables.py:
+    byte j of entry [t][lane] multiplies byte phi = 64 t + 16 (lane >> 4) + j of a sample column; row = lane & 15 stands for
+    the lag offset b = 2 (row >> 2) + ((row & 3) >> 1) inside a block of 8 and the part row & 1 (0 real, 1 imaginary sum);
+    tap k = (phi >> 1) - b, zero outside the 64 taps"""
     lts = _table("WR_LTS_TIME")
     q8 = _int_table("WR_LTS_Q8")
     assert np.array_equal(q8, np.rint(64.0 * lts).astype(np.int64)) and np.abs(q8).max() <= 127
-    words = _int_table("WR_LTS_MFMA_B8").reshape(3, 64, 4)
+    words = _int_table("WR_LTS_MFMA_A8").reshape(3, 64, 4)
+    seen = set()
     for t in range(3):
         for lane in range(64):
             by = np.array([(int(words[t, lane, j >> 2]) >> (8 * (j & 3))) & 0xff for j in range(16)], dtype=np.uint8).view(np.int8)
+            row = lane & 15
+            b, outpart = 2 * (row >> 2) + ((row & 3) >> 1), row & 1
+            seen.add((b, outpart))
             for j in range(16):
                 phi = 64 * t + 16 * (lane >> 4) + j
-                m, part, col = phi // 2, phi % 2, lane & 15
-                k = m - (col & 7)
+                m, part = phi // 2, phi % 2
+                k = m - b
                 want = 0
                 if 0 <= k < 64:
                     qr, qi = q8[2 * k], q8[2 * k + 1]
-                    want = (qi if part else qr) if col < 8 else (qr if part else -qi)
+                    want = (qi if part else qr) if outpart == 0 else (qr if part else -qi)
                 assert by[j] == want, (t, lane, j)
+    assert seen == {(b, p) for b in range(8) for p in range(2)}
 
 
 def test_integer_lts_search_finds_the_peaks_of_the_float_search(orc):

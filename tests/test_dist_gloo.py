@@ -93,6 +93,36 @@ def test_bench_launches_its_own_ranks_world2():
     assert sorted(h["rank"] for h in c["ranks_hosts"]) == [0, 1] and len({h["pid"] for h in c["ranks_hosts"]}) == 2
 
 
+@pytest.mark.timeout(600)
+def test_bench_launches_its_own_ranks_world8():
+    """the same rehearsal at the rank count of BASELINE.json configs[3] (8 GPUs, 1 M frames each) -- eight gloo
+    ranks on the CPU: one JSON line, the collective saw eight ranks in eight processes, every rank ends with the 8 x n_frames PDUs
+    (320-byte rows + 32-byte records) in global frame order, and the ranks draw distinct payloads and distinct noise."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WIFIRX_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    n = 600
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--frames", str(n), "--gather-chunks", "4"], env=env, capture_output=True, text=True, timeout=560)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["data"] == "stub" and j["scaling"] == "weak"
+    assert j["gather_consistent"] is True and j["pdus_gathered"] == 8 * n and j["gather_chunks"] == 4
+    assert j["gathered_bytes_per_rank"] == 8 * (320 + 32) * n
+    c = j["collective"]
+    assert c["backend"] == "gloo" and c["world_size_seen"] == 8 and c["dist_world_size"] == 8
+    assert sorted(h["rank"] for h in c["ranks_hosts"]) == list(range(8)) and len({h["pid"] for h in c["ranks_hosts"]}) == 8
+    pr = j["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(8))
+    assert len({r["payload_seed"] for r in pr}) == 8 and len({r["synth_seed"] for r in pr}) == 8
+
+
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     import subprocess
     import sys
