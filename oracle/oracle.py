@@ -32,7 +32,7 @@ class Params(C.Structure):
                 ("min_plateau", C.c_int32), ("math_mode", C.c_int32), ("max_sym", C.c_int32),
                 ("llr_bits", C.c_int32), ("chan_est", C.c_int32), ("llr_csi", C.c_int32),
                 ("lts_search", C.c_int32), ("no_pair_fallback", C.c_int32), ("dbg_top4", C.c_void_p), ("dbg_mag4", C.c_void_p),
-                ("fallback_cfo_f", C.c_float), ("pad2_", C.c_int32)]
+                ("fallback_cfo_f", C.c_float), ("libm_exact_phase", C.c_int32)]
 
 
 def build(force: bool = False) -> str:
@@ -90,12 +90,15 @@ def _p(a):
 
 
 def make_params(bandwidth=20e6, frequency=5.89e9, threshold=0.56, min_plateau=2,
-                math_mode=MATH_SPEC, max_sym=64, llr_bits=0, chan_est=0, llr_csi=0, lts_search=0, no_pair_fallback=0) -> Params:
+                math_mode=MATH_SPEC, max_sym=64, llr_bits=0, chan_est=0, llr_csi=0, lts_search=0, no_pair_fallback=0,
+                libm_exact_phase=0) -> Params:
     """lts_search (SPEC mode): 0 = rule 6 as the kernels run it, 1 = the exhaustive float32 search over all 320 lags.
     no_pair_fallback: 1 = frames whose LTS search finds no pair are decoded at offset 320 with the previous frame's fine CFO,
-    as upstream's sync_long does (a measurement switch; the build drops them)."""
+    as upstream's sync_long does (a measurement switch; the build drops them).
+    libm_exact_phase (LIBM mode): 1 = the derotation angles formed in double instead of upstream's float32 products (a measurement
+    switch: isolates the angle rounding in the distance between the GPU and the upstream-literal arithmetic)."""
     return Params(bandwidth, frequency, threshold, min_plateau, math_mode, max_sym, llr_bits, chan_est, llr_csi,
-                  lts_search, no_pair_fallback, None, None, 0.0, 0)
+                  lts_search, no_pair_fallback, None, None, 0.0, libm_exact_phase)
 
 
 def demod_batch(iq: np.ndarray, slot_len: int, prm: Params, want_eq=False, n_threads=1, want_csi=False):

@@ -66,7 +66,12 @@ typedef struct orc_params {
     int32_t* dbg_top4;    /* test hook of orc_frame (single-threaded callers only): the four lags handed to the pair search */
     float*   dbg_mag4;    /* ... and their magnitudes (|corr|^2 in SPEC mode, |corr| in LIBM mode); NULL: off */
     float    fallback_cfo_f;
-    int32_t  pad2_;
+    int32_t  libm_exact_phase;  /* LIBM mode only, a measurement switch (tests/test_gpu_configs.py).  0: upstream's literal derotation --
+                           * the angles -cfo_c * m and cfo_f * m are float32 PRODUCTS before sincosf sees them (sync_short /
+                           * sync_long: `exp(gr_complex(0, -d_freq_offset * d_copied))`): at m = 4000 and 0.037 rad / sample the
+                           * angle is 150 rad and its ulp 1.5e-5 rad.  1: the same two rotations with the angles formed and reduced
+                           * in double (sin / cos in double, rounded to float once): what is left of the distance to the GPU is then
+                           * everything BUT upstream's angle rounding. */
 } orc_params;
 
 /* ------------------------------------------------------------------------------------------- */
@@ -885,7 +890,12 @@ void orc_frame(const c32* x, long n_samp, long t, float cfo_c, long L, const orc
                 long m = off0 + i;
                 c32 xs = x_at(x, n_samp, t - 16 + m);
                 float a1 = -cfo_c * (float)m, a2 = (float)m * cfo_f, s1, c1, s2, c2;
-                sincosf(a1, &s1, &c1); sincosf(a2, &s2, &c2);
+                if (prm->libm_exact_phase) {
+                    const double d1 = -(double)cfo_c * (double)m, d2 = (double)m * (double)cfo_f;
+                    s1 = (float)sin(d1); c1 = (float)cos(d1); s2 = (float)sin(d2); c2 = (float)cos(d2);
+                } else {
+                    sincosf(a1, &s1, &c1); sincosf(a2, &s2, &c2);
+                }
                 float complex v = ((xs.re + I * xs.im) * (c1 + I * s1)) * (c2 + I * s2);
                 z[i].re = crealf(v); z[i].im = cimagf(v);
             }

@@ -33,20 +33,30 @@ def _lib():
 
 
 class Fenced:
-    """`nbytes` of device memory with FENCE bytes of 0xA5 before and after it"""
+    """`nbytes` of device memory with FENCE bytes of 0xA5 before and after it (allocated through the library's C ABI: the pytest
+    process holds ONE HIP runtime, the one libwifirx.so and libboxprobe.so link; torch's bundled one stays out of it)"""
 
-    def __init__(self, torch, nbytes, fill=0):
+    def __init__(self, rx, nbytes, fill=0):
         self.n = int(nbytes)
-        self.t = torch.full((2 * FENCE + self.n,), 0xA5, dtype=torch.uint8, device="cuda")
-        self.t[FENCE:FENCE + self.n] = fill
-        self.ptr = self.t.data_ptr() + FENCE
+        self.buf = rx.alloc(2 * FENCE + self.n)
+        host = np.full(2 * FENCE + self.n, 0xA5, dtype=np.uint8)
+        host[FENCE:FENCE + self.n] = fill
+        self.buf.upload(host)
+        self.ptr = self.buf.ptr + FENCE
         assert self.ptr % 256 == 0
 
+    def _host(self):
+        return self.buf.download(np.uint8, 2 * FENCE + self.n)
+
     def fences_intact(self):
-        return bool((self.t[:FENCE] == 0xA5).all().item()) and bool((self.t[FENCE + self.n:] == 0xA5).all().item())
+        h = self._host()
+        return bool((h[:FENCE] == 0xA5).all()) and bool((h[FENCE + self.n:] == 0xA5).all())
 
     def touched(self):
-        return bool((self.t[FENCE:FENCE + self.n] != 0).any().item())
+        return bool((self._host()[FENCE:FENCE + self.n] != 0).any())
+
+    def free(self):
+        self.buf.free()
 
 
 @pytest.mark.parametrize("n_bpsc", [1, 2, 4, 6])
@@ -55,18 +65,18 @@ def test_probe_stays_inside_its_buffers(n_bpsc, with_car):
     """n_slots not a multiple of 4 (the last wave holds one slot), a slot the pattern barely fits, every constellation, with and
     without the `carrier` rows; the sample buffer is the smallest of the three in some cases (n_bpsc 6) and the LLR buffer in
     others (n_bpsc 1): the stream leg must stop at the shorter one."""
-    import torch
+    from wifirx import capi
     lib = _lib()
+    rx = capi.WifiRx(max_sym=8)
     n_slots, lead, n_sym = 1001, 160, 7
     slot_len = lead + 192 + 128 + 80 * (n_sym + 1)             # the shortest slot boxprobe_run accepts
-    x = Fenced(torch, n_slots * slot_len * 8, fill=0)
-    idx = Fenced(torch, n_slots * n_sym * 48)
-    llr = Fenced(torch, n_slots * n_sym * 48 * n_bpsc * 4)
-    car = Fenced(torch, n_slots * n_sym * 48 * 8) if with_car else None
+    x = Fenced(rx, n_slots * slot_len * 8, fill=0)
+    idx = Fenced(rx, n_slots * n_sym * 48)
+    llr = Fenced(rx, n_slots * n_sym * 48 * n_bpsc * 4)
+    car = Fenced(rx, n_slots * n_sym * 48 * 8) if with_car else None
     out = (C.c_double * 12)()
-    torch.cuda.synchronize()
-    rc = lib.boxprobe_run(x.ptr, idx.ptr, llr.ptr, car.ptr if car else None, n_slots, slot_len, lead, n_sym, n_bpsc, 1, out)
-    torch.cuda.synchronize()
+    rx.sync()
+    rc = lib.boxprobe_run(x.ptr, idx.ptr, llr.ptr, car.ptr if car else None, n_slots, slot_len, lead, n_sym, n_bpsc, 1, out)     # (synchronises the device before it returns)
     assert rc == 0
     for name, b in (("x", x), ("idx", idx), ("llr", llr), ("car", car)):
         if b is not None:
@@ -78,25 +88,33 @@ def test_probe_stays_inside_its_buffers(n_bpsc, with_car):
     assert rc == HIP_ERROR_INVALID_VALUE
     assert lib.boxprobe_run(x.ptr, idx.ptr, llr.ptr, None, n_slots, slot_len, lead, n_sym, 3, 1, out) == HIP_ERROR_INVALID_VALUE
     assert lib.boxprobe_run(x.ptr, idx.ptr, llr.ptr, None, 0, slot_len, lead, n_sym, n_bpsc, 1, out) == HIP_ERROR_INVALID_VALUE
+    for b in (x, idx, llr, car):
+        if b is not None:
+            b.free()
+    rx.close()
 
 
 def test_stream_leg_is_clamped_to_the_shorter_buffer():
     """The geometry of the round-4 fault in small: BPSK rows (192 B of LLRs per symbol) against 512 B of samples per symbol -- the bytes
     the kernel reads are 2.7 x what the LLR buffer holds.  out[1] (bytes the stream moved) must not exceed what the two buffers
     allow, and the fence behind `llr` must stand."""
-    import torch
+    from wifirx import capi
     lib = _lib()
+    rx = capi.WifiRx(max_sym=8)
     n_slots, lead, n_sym, n_bpsc = 4099, 160, 50, 1
     slot_len = 4608
-    x = Fenced(torch, n_slots * slot_len * 8)
-    idx = Fenced(torch, n_slots * n_sym * 48)
-    llr = Fenced(torch, n_slots * n_sym * 48 * n_bpsc * 4)
+    x = Fenced(rx, n_slots * slot_len * 8)
+    idx = Fenced(rx, n_slots * n_sym * 48)
+    llr = Fenced(rx, n_slots * n_sym * 48 * n_bpsc * 4)
     out = (C.c_double * 12)()
+    rx.sync()
     rc = lib.boxprobe_run(x.ptr, idx.ptr, llr.ptr, None, n_slots, slot_len, lead, n_sym, n_bpsc, 1, out)
-    torch.cuda.synchronize()
     assert rc == 0
     assert llr.fences_intact() and idx.fences_intact() and x.fences_intact()
     rd_wanted = n_slots * ((n_sym + 3) * 512 + (lead + 64) // 16 * 128 + 6 * 512)
     assert rd_wanted > 2 * llr.n                                    # the unclamped stream would have run far past `llr`
     pieces = out[1] / 16.0
     assert pieces <= 2 * (llr.n // 16) + 1                          # read + written pieces: at most one each per piece of `llr`
+    for b in (x, idx, llr):
+        b.free()
+    rx.close()

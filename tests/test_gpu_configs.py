@@ -158,10 +158,33 @@ def _gpu_vs_libm(orc, geo, cfo_max, seed):
     complete = int(((r["frames"]["flags"] & capi.F_COMPLETE) != 0).sum())
     n_dec = int(r["idx"].size)
     diff = int((r["idx"] != libm["idx"]).sum())
-    llr_rel = float(np.abs(r["llr"] - libm["llr"]).max() / np.abs(libm["llr"]).max())
-    eq_rel = float(np.abs(r["carrier"] - libm["eq"]).max() / np.abs(libm["eq"]).max())
+
+    def dist(a, ref):
+        """max |a - ref| over the batch, relative to the largest |ref| (the reading the earlier rounds reported), and element by
+        element relative to |ref| with a floor of 1e-3 of the largest (the stricter reading of "relative")"""
+        d = np.abs(a - ref)
+        big = float(np.abs(ref).max())
+        return float(d.max() / big), float((d / np.maximum(np.abs(ref), 1e-3 * big)).max())
+
+    llr_rel, llr_elem = dist(r["llr"], libm["llr"])
+    eq_rel, eq_elem = dist(r["carrier"], libm["eq"])
+    # the same against LIBM with the derotation angles formed in double (oracle switch libm_exact_phase): everything upstream's
+    # arithmetic does EXCEPT rounding -cfo_c * m and cfo_f * m to float32 before the sine / cosine
+    ex = orc.demod_batch(x, slot, orc.make_params(max_sym=tx.n_sym, llr_bits=nb, math_mode=orc.MATH_LIBM, libm_exact_phase=1),
+                         want_eq=True, n_threads=os.cpu_count() or 1)
+    same_ex = bool(np.array_equal(r["frames"]["trigger"], ex["frames"]["trigger"]) and
+                   np.array_equal(r["frames"]["frame_start"], ex["frames"]["frame_start"]) and
+                   np.array_equal(r["frames"]["flags"], ex["frames"]["flags"]))
+    llr_rel_x, llr_elem_x = dist(r["llr"], ex["llr"])
+    eq_rel_x, eq_elem_x = dist(r["carrier"], ex["eq"])
+    # how far upstream's literal arithmetic is from ITSELF with exact angles: the size of the angle rounding alone
+    lit_rel, lit_elem = dist(libm["llr"], ex["llr"])
     return dict(frames=n, frames_complete=complete, same_trigger_start_flags=same_frames, decisions=n_dec,
-                decisions_differing=diff, llr_max_rel=llr_rel, eq_max_rel=eq_rel)
+                decisions_differing=diff, llr_max_rel=llr_rel, eq_max_rel=eq_rel, llr_elem_rel=llr_elem, eq_elem_rel=eq_elem,
+                exact_phase=dict(same_trigger_start_flags=same_ex, decisions_differing=int((r["idx"] != ex["idx"]).sum()),
+                                 llr_max_rel=llr_rel_x, eq_max_rel=eq_rel_x, llr_elem_rel=llr_elem_x, eq_elem_rel=eq_elem_x),
+                upstream_literal_vs_its_own_exact_phase=dict(llr_max_rel=lit_rel, llr_elem_rel=lit_elem,
+                                                             decisions_differing=int((libm["idx"] != ex["idx"]).sum())))
 
 
 @pytest.mark.timeout(600)
@@ -193,12 +216,15 @@ def test_distance_to_upstream_literal_arithmetic_at_20ppm(orc):
         assert d["same_trigger_start_flags"], name
         assert d["decisions_differing"] <= max(2, d["decisions"] // 500_000), (name, d)    # a sample on a slicer boundary
         assert d["llr_max_rel"] <= bound[name], (name, d)
+        # with upstream's angle rounding taken out (libm_exact_phase) the distance is north_star's 1e-5
+        assert d["exact_phase"]["same_trigger_start_flags"], name
+        assert d["exact_phase"]["llr_max_rel"] <= 1e-5 and d["exact_phase"]["eq_max_rel"] <= 1e-5, (name, d)
     _record("distance_to_libm_20ppm", rec)
 
 
 def _record(key, value):
-    """keeps what the tests measured: gpurun_out/r04_gpu_configs.json (copied to profiles/ by the builder)"""
-    path = os.path.join(ROOT, "gpurun_out", "r04_gpu_configs.json")
+    """keeps what the tests measured: gpurun_out/r05_gpu_configs.json (copied to profiles/ by the builder)"""
+    path = os.path.join(ROOT, "gpurun_out", "r05_gpu_configs.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         cur = {}
