@@ -73,7 +73,7 @@ struct wifirx_handle {
     int64_t  stream_batch = 0;      // WIFIRX_P_STREAM_BATCH
     uint32_t decode_small_max = WR_DECODE_SMALL_MAX;   // WIFIRX_P_DECODE_SMALL_MAX
     uint32_t decode_fpw = 0;        // WIFIRX_DECODE_FPW (environment, tests): frames per wave of the throughput decoder
-    int      decode_ovl = -1;       // WIFIRX_DECODE_OVL: 1 / 0 = always / never overlap trace-back and the next task's add-compare-select
+    int      decode_ovl = -1;       // WIFIRX_DECODE_OVL: 0 = trace-back behind each task, 1 = under the wave's next task, 2 = speculative walks under the task's own add-compare-select; -1: by batch size
     int      decode_q = -1;         // WIFIRX_DECODE_Q (environment, tests): 1 / 0 = always / never the four-frames-per-lane decoder; -1: by batch size
     int32_t  llr_csi = 0;           // WIFIRX_P_LLR_CSI
     int32_t  stream_want_idx = 1;   // WIFIRX_P_STREAM_IDX
@@ -89,7 +89,7 @@ struct wifirx_handle {
     int    test_fail_alloc = 0, test_alloc_count = 0;      // WIFIRX_TEST_FAIL_ALLOC (allocation-failure tests)
     size_t test_decode_budget = 0;                         // WIFIRX_TEST_DECODE_BUDGET: bytes of survivor scratch a decode call may hold (tests)
     int    test_fail_decode_scratch = 0;                   // WIFIRX_TEST_FAIL_DECODE_SCRATCH: the next k scratch allocations fail (tests)
-    uint32_t dec_last_waves = 0; bool dec_last_overlap = false;      // what the last throughput decode ran with (WIFIRX_TRACE)
+    uint32_t dec_last_waves = 0; bool dec_last_overlap = false; int dec_last_mode = 0;      // what the last throughput decode ran with (WIFIRX_TRACE)
     int    test_fail_carry = 0, test_carry_count = 0;      // WIFIRX_TEST_FAIL_CARRY (a failure behind the commit of a stream pass)
     bool   stream_dead = false;                            // the carry step failed after it had begun to move the sample buffer
     std::string stream_dead_msg;
@@ -214,7 +214,7 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
     if (const char* e = std::getenv("WIFIRX_DECODE_SMALL_MAX")) h->decode_small_max = (uint32_t)std::strtoul(e, nullptr, 10);   // tests pick the decode kernel with this
     if (const char* e = std::getenv("WIFIRX_DECODE_FPW")) h->decode_fpw = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("WIFIRX_DECODE_Q")) h->decode_q = std::atoi(e) != 0;
-    if (const char* e = std::getenv("WIFIRX_DECODE_OVL")) h->decode_ovl = std::atoi(e) != 0;
+    if (const char* e = std::getenv("WIFIRX_DECODE_OVL")) h->decode_ovl = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("WIFIRX_TEST_FAIL_ALLOC")) h->test_fail_alloc = std::atoi(e);
     if (const char* e = std::getenv("WIFIRX_TEST_FAIL_CARRY")) h->test_fail_carry = std::atoi(e);
     if (const char* e = std::getenv("WIFIRX_TEST_DECODE_BUDGET")) h->test_decode_budget = (size_t)std::strtoull(e, nullptr, 10);

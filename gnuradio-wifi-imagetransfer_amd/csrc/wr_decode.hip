@@ -829,10 +829,73 @@ __device__ __forceinline__ void tb_pending_group(TbPending& pend, int lane, wifi
         }
     }
 }
+
+// The trace-back of a task overlapped with ITS OWN add-compare-select (template MODE = 2, round 5).  The overlap above hides the
+// trace-back of a task under the arithmetic of the wave's NEXT task -- with two tasks per wave (a million frames = 3 907 tasks over
+// 2 048 waves) every second trace-back still ran on its own, all waves at once: 10 GB of survivor reads, 1.9 of 12.1 ms.  Here every
+// block of 96 steps is walked back SPECULATIVELY while the next block's add-compare-select runs: when the trellis has reached
+// boundary B_(j+1) = 96 (j + 1), a walk starts there in the state with the smallest metric (any state would do for correctness),
+// goes back through block j six steps per group of six trellis steps, and leaves the block's 96 decoded bits.  Survivor paths
+// merge: the walk from B_(j+2) arrives at B_(j+1) in the state the walk before it STARTED from unless that state was not on the
+// final path -- the link of block j + 1 is then marked broken.  After the last trellis step the true trace-back starts in the best
+// final state and stops at the first boundary B_j where it stands in the recorded start state S_j of walk j - 1 and no link below
+// is broken: from there down its path IS the chain of the speculative walks, whose bits are already in place.  Exact -- a walk
+// that was off the final path is walked over again by the final one --, and what runs exposed is one block (plus the steps
+// behind the last boundary) instead of the whole trellis.  Tasks whose frames differ in length are walked back on the spot.
+struct SpecWalk {
+    bool     active;                  // wave-uniform
+    int      st[4];
+    uint32_t aw[4][3];
+    int      blk, grp;                // wave-uniform: the block being walked, the next group of six in it
+};
+
+// Six steps of the speculative walk.  When the block is through: its three decoded words per frame leave, and the state the walk
+// arrived in at the block's lower boundary is compared with the start state of the walk before (link_ref, a byte per frame): a
+// mismatch marks the link of this block broken (fb[h] = lowest broken block).
+__device__ __forceinline__ void spec_walk_group(SpecWalk& sw, int lane, const uint32_t* __restrict__ surv, uint32_t* __restrict__ dbits,
+                                                uint32_t link_ref, int (&fb)[4])
+{
+    const uint32_t* srow = surv + ((size_t)(sw.blk * 96 + 6 * sw.grp) * 64 + lane) * 8;
+    uint32_t l0[6], u0[6], l1[6], u1[6], l2[6], u2[6], l3[6], u3[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint4* sp = reinterpret_cast<const uint4*>(srow + (size_t)k * 512);
+        const uint4 a = sp[0], b = sp[1];
+        l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        const uint32_t v = __builtin_bitreverse32((uint32_t)sw.st[h]) >> 26;      // u_(t-5) .. u_t, oldest in bit 0
+        sw.aw[h][2] = __builtin_amdgcn_alignbit(sw.aw[h][2], sw.aw[h][1], 26);
+        sw.aw[h][1] = __builtin_amdgcn_alignbit(sw.aw[h][1], sw.aw[h][0], 26);
+        sw.aw[h][0] = (sw.aw[h][0] << 6) | v;
+    }
+#pragma unroll
+    for (int q = 5; q >= 0; q--) {
+        const uint32_t h0 = WR_DQ_PICKP(sw.st[0], l0[q], u0[q]), h1 = WR_DQ_PICKP(sw.st[1], l1[q], u1[q]);
+        const uint32_t h2 = WR_DQ_PICKP(sw.st[2], l2[q], u2[q]), h3 = WR_DQ_PICKP(sw.st[3], l3[q], u3[q]);
+        sw.st[0] = (sw.st[0] >> 1) | (int)(h0 << 5);
+        sw.st[1] = (sw.st[1] >> 1) | (int)(h1 << 5);
+        sw.st[2] = (sw.st[2] >> 1) | (int)(h2 << 5);
+        sw.st[3] = (sw.st[3] >> 1) | (int)(h3 << 5);
+    }
+    if (--sw.grp < 0) {
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+#pragma unroll
+            for (int h = 0; h < 4; h++) dbits[(size_t)(sw.blk * 3 + w) * 256 + 64 * h + lane] = sw.aw[h][w];
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+            if (sw.st[h] != (int)((link_ref >> (8 * h)) & 63u) && sw.blk < fb[h]) fb[h] = sw.blk;
+        sw.active = false;
+    }
+}
 #undef WR_DQ_PICKP
 
-template <int ROWS, bool OVL>        // LDS rows per wave: 32 (rates up to 16-QAM: 8 staged words x 4), 48 (64-QAM: one symbol of 12 words)
-__global__ __launch_bounds__(256, OVL ? 2 : (ROWS == 32 ? 4 : 3))
+// MODE: 0 = a task's trace-back behind its add-compare-select; 1 = overlapped with the wave's next task (above); 2 = speculative
+// walks overlapped with the task's own add-compare-select (above).
+template <int ROWS, int MODE>        // LDS rows per wave: 32 (rates up to 16-QAM: 8 staged words x 4), 48 (64-QAM: one symbol of 12 words)
+__global__ __launch_bounds__(256, MODE ? 2 : (ROWS == 32 ? 4 : 3))
 void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
                      const uint32_t* __restrict__ hbits_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
                      uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total,
@@ -840,6 +903,7 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
 {
     // the current OFDM symbols of the wave's frames: row 4 w + 2 c + g (w = word of the staged 8-word block, c = 0: frames
     // h = 0, 1; c = 1: frames h = 2, 3; g = 16-bit plane of the word) = plane of the first frame | that of the second << 16
+    constexpr bool OVL = MODE == 1, SPEC = MODE == 2;
     __shared__ uint32_t sym_all[4][ROWS * 64];
     __shared__ FinishTables ft;
     build_finish_tables(ft);
@@ -851,6 +915,7 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
     const uint32_t sym_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)sym_all[wv]);
     const size_t n_data_cap = n_steps_cap;
     // scratch of the wave: [step][lane][8 words] of survivor bits + [word][h][lane] of decoded bits; OVL: two such halves
+    // (SPEC: + [boundary][lane] the start states of the speculative walks, a byte per frame)
     const size_t half_words = n_data_cap * 512 + (n_data_cap / 32 + 2) * 256;
     uint32_t* const scr0 = reinterpret_cast<uint32_t*>(scratch + (size_t)wave * scratch_stride);
     int buf = 0;
@@ -900,9 +965,17 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
 
         uint32_t* surv = scr0 + (OVL ? (size_t)buf * half_words : 0);
         uint32_t* dbits = surv + n_data_cap * 512;
+        uint32_t* rec = dbits + (n_data_cap / 32 + 2) * 256;         // SPEC only (the host sized the slice for it)
         uint32_t pm[64];
         int best[4] = { 0, 0, 0, 0 };
         int tt_u = 0, sym_u = 0, since_norm = 0;
+        // fast trace-back (blocks of 96 steps) when all frames of the wave run the full n_max steps
+        const bool uni = __all(n_data[0] == n_max && n_data[1] == n_max && n_data[2] == n_max && n_data[3] == n_max);
+        const int n_fast = uni ? (n_max / 96) * 96 : 0;
+        SpecWalk sw;
+        sw.active = false;
+        int fb[4] = { 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff };     // SPEC: lowest block whose link to the walk below is broken
+        uint32_t cur_start = 0u, link_ref = 0u;                              // SPEC: start states (a byte per frame) of the running walk / of the one before
         // one group of six trellis steps; `first`: the group without comparisons (steps 0..5)
         auto group = [&](auto first_tag, const int tg) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -1033,6 +1106,36 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
             }
             tt_u += 6;
             if (OVL && pend.active) tb_pending_group(pend, lane, frames, psdu_all, psdu_stride, ft);
+            if (SPEC && n_fast > 0) {
+                if (sw.active) spec_walk_group(sw, lane, surv, dbits, link_ref, fb);
+                const int done = tg + 6;
+                if (done % 96 == 0 && done + 96 <= n_max) {
+                    // boundary B_j, j = done / 96, with another whole block of trellis steps ahead: the walk through block j - 1
+                    // starts in the state with the smallest metric (register phase 0: pm[s] is state s)
+                    uint32_t S = 0u;
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const int sh = 8 * WR_DQ_BYTE(h);
+                        uint32_t bm = (pm[0] >> sh) & 0xffu;
+                        int bs = 0;
+#pragma unroll
+                        for (int s2 = 1; s2 < 64; s2++) {
+                            const uint32_t v = (pm[s2] >> sh) & 0xffu;
+                            if (v < bm) { bm = v; bs = s2; }
+                        }
+                        sw.st[h] = bs;
+                        S |= (uint32_t)bs << (8 * h);
+#pragma unroll
+                        for (int w = 0; w < 3; w++) sw.aw[h][w] = 0u;
+                    }
+                    rec[(size_t)(done / 96) * 64 + lane] = S;
+                    link_ref = cur_start;
+                    cur_start = S;
+                    sw.blk = done / 96 - 1;
+                    sw.grp = 15;
+                    sw.active = true;
+                }
+            }
         };
         group(std::true_type{}, 0);
         for (int tg = 6; tg < n_max; tg += 6) group(std::false_type{}, tg);
@@ -1046,8 +1149,6 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
         {
             int st[4] = { best[0], best[1], best[2], best[3] };
             uint32_t word[4] = { 0u, 0u, 0u, 0u };
-            const bool uni = __all(n_data[0] == n_max && n_data[1] == n_max && n_data[2] == n_max && n_data[3] == n_max);
-            const int n_fast = uni ? (n_max / 96) * 96 : 0;
 #define WR_DQ_PICK(H, LO, HI)                                                                             \
             (__builtin_amdgcn_ubfe((((st[H] & 32) ? (HI) : (LO)) ^ 0x77777777u), (uint32_t)((st[H] & 31) ^ 3), 1u))
             for (int t1 = n_max - 1; t1 >= n_fast; t1 -= 4) {
@@ -1133,6 +1234,17 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
                 for (int w = 0; w < 3; w++)
 #pragma unroll
                     for (int h = 0; h < 4; h++) dbits[(size_t)(blk * 3 + w) * 256 + 64 * h + lane] = aw[h][w];
+                if (SPEC && blk > 0) {
+                    // Boundary B_blk: a speculative walk started here (every boundary below the last whole block has one) in the states
+                    // S.  A frame whose true path stands in that state, with every link below intact, has joined the chain of the
+                    // walks: what lies below is decoded already.  The wave stops when all its frames have (from then on the
+                    // paths coincide, so a frame that joined earlier only rewrote its own bits).
+                    const uint32_t S = rec[(size_t)blk * 64 + lane];
+                    bool joined = true;
+#pragma unroll
+                    for (int h = 0; h < 4; h++) joined = joined && st[h] == (int)((S >> (8 * h)) & 63u) && fb[h] >= blk;
+                    if (__all(joined)) break;
+                }
             }
 #undef WR_DQ_PICK
         }
@@ -1423,12 +1535,14 @@ extern "C" hipError_t wr_launch_decode_q(hipStream_t st, uint32_t n_slots, uint3
                                          size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves, uint32_t frames_per_wave,
                                          const uint32_t* perm, uint32_t n_virtual, int has_64qam, int overlap)
 {
+    // overlap: 0 = trace-back behind the task, 1 = under the wave's next task (double scratch slice), 2 = speculative walks under the
+    // task's own add-compare-select (slice + (n_steps_cap / 96 + 2) x 256 bytes of start states)
     if (n_slots == 0 || n_waves == 0) return hipSuccess;
     if (!perm) n_virtual = n_slots;
-#define WR_LAUNCH_Q(ROWS, OVL) hipLaunchKernelGGL((wr::decode_q_kernel<ROWS, OVL>), dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, \
-                                                  frames, hbits, psdu, psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual)
-    if (has_64qam) { if (overlap) WR_LAUNCH_Q(48, true); else WR_LAUNCH_Q(48, false); }
-    else           { if (overlap) WR_LAUNCH_Q(32, true); else WR_LAUNCH_Q(32, false); }
+#define WR_LAUNCH_Q(ROWS, MODE) hipLaunchKernelGGL((wr::decode_q_kernel<ROWS, MODE>), dim3((n_waves + 3) / 4), dim3(256), 0, st, n_slots, max_sym, \
+                                                   frames, hbits, psdu, psdu_stride, scratch, scratch_stride, n_steps_cap, n_waves, frames_per_wave, perm, n_virtual)
+    if (has_64qam) { if (overlap == 2) WR_LAUNCH_Q(48, 2); else if (overlap) WR_LAUNCH_Q(48, 1); else WR_LAUNCH_Q(48, 0); }
+    else           { if (overlap == 2) WR_LAUNCH_Q(32, 2); else if (overlap) WR_LAUNCH_Q(32, 1); else WR_LAUNCH_Q(32, 0); }
 #undef WR_LAUNCH_Q
     return hipGetLastError();
 }

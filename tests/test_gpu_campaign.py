@@ -76,6 +76,11 @@ def test_random_frames_four_frames_per_lane_decoder(monkeypatch):
     _record("frames_seed306_four_frames_per_lane_decoder", res)
     for name, v in res["equalisers"].items():
         assert v["total_mismatches"] == 0, (name, v["mismatches"])
+    monkeypatch.setenv("WIFIRX_DECODE_OVL", "2")          # speculative walks under the task's own add-compare-select (round 5)
+    res = pc.run(20000, 309, equalisers=(0, 1), decode_small_max=0)
+    _record("frames_seed309_four_frames_per_lane_decoder_speculative", res)
+    for name, v in res["equalisers"].items():
+        assert v["total_mismatches"] == 0, (name, v["mismatches"])
     monkeypatch.setenv("WIFIRX_DECODE_FPW", "0")
     res = pc.run(1200, 307, long_frames=True, equalisers=(0,), decode_small_max=0)
     _record("long_frames_seed307_four_frames_per_lane_decoder", res)

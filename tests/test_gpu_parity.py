@@ -89,8 +89,8 @@ def test_decode_mac_full_waves(capi, orc, monkeypatch, encoding, plen, snr):
         assert ((o["frames"]["flags"] & orc.F_CRC_OK) != 0).all() and np.array_equal(r["psdu"][:, :plen], tx.psdu)
 
 
-@pytest.mark.parametrize("overlap", [0, 1])
-@pytest.mark.parametrize("encoding,plen,snr", [(2, 294, 25.0), (2, 294, 5.0), (0, 60, 6.0), (7, 294, 19.5), (5, 100, 13.0), (4, 333, 11.0)])
+@pytest.mark.parametrize("overlap", [0, 1, 2])
+@pytest.mark.parametrize("encoding,plen,snr", [(2, 294, 25.0), (2, 294, 5.0), (2, 294, 2.5), (0, 60, 6.0), (7, 294, 19.5), (5, 100, 13.0), (4, 333, 11.0)])
 def test_decode_mac_four_frames_per_lane(capi, orc, monkeypatch, encoding, plen, snr, overlap):
     """decode_q_kernel (four frames per lane, byte path metrics, 256 frames per wave: what batches of a million frames
     take) forced onto a small batch with every frame position of its waves filled: byte for byte the oracle's PSDUs, at
@@ -98,8 +98,10 @@ def test_decode_mac_four_frames_per_lane(capi, orc, monkeypatch, encoding, plen,
     monkeypatch.setenv("WIFIRX_DECODE_SMALL_MAX", "0")
     monkeypatch.setenv("WIFIRX_DECODE_Q", "1")
     monkeypatch.setenv("WIFIRX_DECODE_FPW", "256")
-    # overlap = 1: the trace-back of a task runs interleaved with the add-compare-select of the wave's next task (what a
-    # million-frame batch takes); 1400 frames = 6 tasks on 3 waves: deferred, interleaved and drained trace-backs all occur
+    # overlap = 1: the trace-back of a task runs interleaved with the add-compare-select of the wave's next task; 1400 frames = 6
+    # tasks on 3 waves: deferred, interleaved and drained trace-backs all occur.  overlap = 2 (what a million-frame batch takes since
+    # round 5): every block of 96 steps is walked back speculatively under the task's own next block, the true trace-back joins the
+    # chain of those walks -- at 25 dB after one block, at 2.5 .. 6 dB (start states off the final path, broken links) after many
     monkeypatch.setenv("WIFIRX_DECODE_OVL", str(overlap))
     n = 1400 if overlap else 600                              # full waves + one partly filled
     iq, slot_len, tx = make_slots(n, encoding, psdu_len=plen, snr_db=snr, seed=300 + encoding)
