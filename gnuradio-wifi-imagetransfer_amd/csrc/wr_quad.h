@@ -75,8 +75,8 @@ namespace wr {
 #define WR_QLDS_SCRATCH_EQ(EQ) ((EQ) == WIFIRX_EQ_COMB ? 768 : WR_QLDS_LONG)
 #define WR_QLDS_H(S)       (S)                        // 4 x 64 float2: channel estimate, lane-private slots
 #define WR_QLDS_TW(S)      (WR_QLDS_H(S) + 512)       // 6 x 16 float2: stage-1/2 twiddles by row lane
-#define WR_QLDS_PREV(S)    (WR_QLDS_TW(S) + 192)      // 4 rows x 4 float2: pilots of the previous symbol
-#define WR_QLDS_W(S)       (WR_QLDS_PREV(S) + 32)     // 4 x 64 floats: |H|^2 of the LS estimate (LLR weight, lane-private slots)
+#define WR_QLDS_PREV(S)    (WR_QLDS_TW(S) + 192)      // 4 rows x 4 float2: pilots of the previous symbol (LMS / COMB / STA: rows of 6 float2, the fifth = the frame's phase increment Qp)
+#define WR_QLDS_W(S)       (WR_QLDS_PREV(S) + 48)     // 4 x 64 floats: |H|^2 of the LS estimate (LLR weight, lane-private slots)
 #define WR_QLDS_PF(S)      (WR_QLDS_W(S))             // the prefetch buffer of the usual output set's loops: the weight area (idle there: weights are an XK output) + WR_QLDS_PFX
 #define WR_QLDS_STAT(S)    (WR_QLDS_W(S) + 256 + WR_QLDS_PFX)       // 4 rows x 4 floats: running sums of |y|, |y|^2, |y|^4 (sym_stats output)
 #define WR_QLDS_FLOATS(S)  (WR_QLDS_STAT(S) + 16)     // per wave; the preamble phase uses the first 1536 floats for two frames' samples
@@ -839,7 +839,12 @@ __device__ __forceinline__ void store_word(uint8_t* p, uint32_t v)
 // shape; the kernel follows since the data loop was slimmed down: -3 % on config 2, -13 % on the config-3 geometry, -5 % on
 // long 16-QAM frames.  Same values, same addresses.
 // Requires (caller, wave-uniform): decisions and LLRs wanted by every active row, no weights, idx 4-byte and llr 16-byte aligned.
-template <int NB>
+// OFF32 (LMS / COMB / STA instances): every piece is addressed by the row base from scalar registers + a 32-bit offset of its own.
+// Written as a pointer sum (lp + 256 k), the compiler keeps the 64-bit address of a piece in a register pair across the loop; in
+// those instances the pair was spilled, and its reload inside the loop is a vector memory operation the counted wait of the
+// prefetch cannot skip (tests/test_isa_prefetch_wait.py; LMS -6 %).  The LS instances have the registers and lose 0.8 % (plane
+// output) to the extra additions: they keep the pointer sum (profiles/r05_ab_spills_in_prefetch_loops.txt).
+template <int NB, bool OFF32 = false>
 __device__ __forceinline__ void store_bins_lines(const c32 (&Y)[4], const int (&carrier)[4], bool ok, int q,
                                                  uint8_t* __restrict__ idx, float* __restrict__ llr,
                                                  uint32_t row_o, uint32_t row_l, float* stage, int row, int r)
@@ -901,12 +906,16 @@ __device__ __forceinline__ void store_bins_lines(const c32 (&Y)[4], const int (&
     const uint32_t d = reinterpret_cast<const uint32_t*>(irow)[r < 12 ? r : 0];
     __builtin_amdgcn_wave_barrier();
     if (ok) {
-        char* lp = reinterpret_cast<char*>(llr) + (uint32_t)((row_l + (uint32_t)(q * 48 * NB)) * 4u + 16u * r);
+        char* const lb = reinterpret_cast<char*>(llr);
+        const uint32_t lo = (row_l + (uint32_t)(q * 48 * NB)) * 4u + 16u * r;
+        char* const lp = reinterpret_cast<char*>(llr) + (uint32_t)((row_l + (uint32_t)(q * 48 * NB)) * 4u + 16u * r);
+#define WR_PIECE_AT(K) (OFF32 ? lb + (uint32_t)(lo + 256u * (K)) : lp + 256 * (K))
         if (NK > 1 || r < TAIL)            store_piece(lp, p0);
-        if (NK > 2 || (NK == 2 && r < TAIL)) store_piece(lp + 256, p1);
-        if (NK > 3 || (NK == 3 && r < TAIL)) store_piece(lp + 512, p2);
-        if (NK > 4 || (NK == 4 && r < TAIL)) store_piece(lp + 768, p3);
-        if (NK == 5 && r < TAIL)             store_piece(lp + 1024, p4);
+        if (NK > 2 || (NK == 2 && r < TAIL)) store_piece(WR_PIECE_AT(1), p1);
+        if (NK > 3 || (NK == 3 && r < TAIL)) store_piece(WR_PIECE_AT(2), p2);
+        if (NK > 4 || (NK == 4 && r < TAIL)) store_piece(WR_PIECE_AT(3), p3);
+        if (NK == 5 && r < TAIL)             store_piece(WR_PIECE_AT(4), p4);
+#undef WR_PIECE_AT
         if (r < 12) store_word(idx + (row_o + (uint32_t)(q * 48) + 4u * r), d);
     }
 }
@@ -917,7 +926,7 @@ __device__ __forceinline__ void store_bins_lines(const c32 (&Y)[4], const int (&
 // branches); the constellation is compile time.  Same values, same addresses as store_bins().  For QPSK rows without weights the
 // LLR row IS the carrier row (re, im per carrier): the pieces are stored twice, not staged twice.
 // Requires (caller, wave-uniform): idx 4-byte, llr and car 16-byte aligned rows; has_llr = every active row wants LLRs.
-template <int NB>
+template <int NB, bool OFF32 = false>      // OFF32: as store_bins_lines
 __device__ __forceinline__ void store_rows_x(const c32 (&Y)[4], const int (&carrier)[4], bool ok, int q,
                                              uint8_t* __restrict__ idx, float* __restrict__ llr, float2* __restrict__ car,
                                              bool has_idx, bool has_llr, bool has_car, bool csi, const float* Wl,
@@ -969,12 +978,16 @@ __device__ __forceinline__ void store_rows_x(const c32 (&Y)[4], const int (&carr
         __builtin_amdgcn_wave_barrier();
         if (ok) {
             if (has_llr) {
-                char* lp = reinterpret_cast<char*>(llr) + (uint32_t)((row_l + (uint32_t)(q * 48 * NB)) * 4u + 16u * r);
+                char* const lb = reinterpret_cast<char*>(llr);
+                const uint32_t lo = (row_l + (uint32_t)(q * 48 * NB)) * 4u + 16u * r;
+                char* const lp = reinterpret_cast<char*>(llr) + (uint32_t)((row_l + (uint32_t)(q * 48 * NB)) * 4u + 16u * r);
+#define WR_PIECE_AT(K) (OFF32 ? lb + (uint32_t)(lo + 256u * (K)) : lp + 256 * (K))
                 if (NK > 1 || r < TAIL)            store_piece(lp, p0);
-                if (NK > 2 || (NK == 2 && r < TAIL)) store_piece(lp + 256, p1);
-                if (NK > 3 || (NK == 3 && r < TAIL)) store_piece(lp + 512, p2);
-                if (NK > 4 || (NK == 4 && r < TAIL)) store_piece(lp + 768, p3);
-                if (NK == 5 && r < TAIL)             store_piece(lp + 1024, p4);
+                if (NK > 2 || (NK == 2 && r < TAIL)) store_piece(WR_PIECE_AT(1), p1);
+                if (NK > 3 || (NK == 3 && r < TAIL)) store_piece(WR_PIECE_AT(2), p2);
+                if (NK > 4 || (NK == 4 && r < TAIL)) store_piece(WR_PIECE_AT(3), p3);
+                if (NK == 5 && r < TAIL)             store_piece(WR_PIECE_AT(4), p4);
+#undef WR_PIECE_AT
             }
             if (has_idx && r < 12) store_word(idx + (row_o + (uint32_t)(q * 48) + 4u * r), d);
         }
@@ -995,9 +1008,16 @@ __device__ __forceinline__ void store_rows_x(const c32 (&Y)[4], const int (&carr
             __builtin_amdgcn_wave_barrier();
         }
         if (ok) {
-            char* cp = reinterpret_cast<char*>(car) + (uint32_t)((row_o + (uint32_t)(q * 48)) * 8u + 16u * r);
-            store_piece(cp, p0);
-            if (r < 8) store_piece(cp + 256, p1);
+            if (OFF32) {
+                char* const cb = reinterpret_cast<char*>(car);
+                const uint32_t co = (row_o + (uint32_t)(q * 48)) * 8u + 16u * r;
+                store_piece(cb + co, p0);
+                if (r < 8) store_piece(cb + (uint32_t)(co + 256u), p1);
+            } else {
+                char* cp = reinterpret_cast<char*>(car) + (uint32_t)((row_o + (uint32_t)(q * 48)) * 8u + 16u * r);
+                store_piece(cp, p0);
+                if (r < 8) store_piece(cp + 256, p1);
+            }
         }
     }
 }
@@ -1163,6 +1183,14 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     // mod 2^64 (a 64 x 32-bit product where a phasor is formed from it, spec rule 8).
     const double theta_d = (double)cfo_f - (double)cfo_c;
     const unsigned long long Qp = (unsigned long long)(long long)__builtin_rint(theta_d * WR_TWO_OVER_PI_D * 4611686018427387904.0);
+    // LMS / COMB / STA: ... kept in LDS for the data symbols, behind the row's previous pilots (every row's lane 0 writes its
+    // frame's; a symbol that forms exact phasors -- every eighth -- reads it back): two registers fewer across the loops.  In these
+    // instances the pair was spilled and reloaded INSIDE the prefetch loops (tests/test_isa_prefetch_wait.py); the LS instance has
+    // the registers, and the read would cost it 1 % (profiles/r05_ab_spills_in_prefetch_loops.txt).
+    constexpr bool QP_LDS = EQ != WIFIRX_EQ_LS;
+    constexpr int PVS = QP_LDS ? 6 : 4;                         // float2 per row of the previous-pilot area (16-byte aligned rows)
+    uint2* const qpl = reinterpret_cast<uint2*>(qlds + WR_QLDS_PREV(WR_QLDS_SCRATCH_EQ(EQ))) + PVS * (lane >> 4) + 4;
+    if (QP_LDS && (lane & 15) == 0) *qpl = make_uint2((uint32_t)Qp, (uint32_t)(Qp >> 32));
     c32 u16;                                                   // exp(j theta 16)
     {
         const unsigned long long q16 = Qp * 16ull;
@@ -1194,7 +1222,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     float* stl = qlds + WR_QLDS_STAT(QS) + 4 * row;                           // the row's running sums (lane r = 0 updates them)
     if (stat_all != nullptr && r < 4) stl[r] = 0.0f;
     float2* Hl = reinterpret_cast<float2*>(qlds + WR_QLDS_H(QS)) + lane;      // element j at Hl[64 j]
-    float2* pvl = reinterpret_cast<float2*>(qlds + WR_QLDS_PREV(QS)) + 4 * row;
+    float2* pvl = reinterpret_cast<float2*>(qlds + WR_QLDS_PREV(QS)) + PVS * row;
     float* Wl = qlds + WR_QLDS_W(QS) + lane;                                  // element j at Wl[64 j]
     float2* DHl = reinterpret_cast<float2*>(qlds + (COMB ? WR_QLDS_DH(QS) : WR_QLDS_H(QS))) + lane;   // COMB: d_H; else = Hl
     float cw[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, cu[4] = { 0.0f, 0.0f, 0.0f, 0.0f };           // COMB: interpolation weights
@@ -1202,16 +1230,18 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
 #pragma unroll
         for (int j = 0; j < 4; j++) { cw[j] = WR_COMB_W[r + 16 * j]; cu[j] = WR_COMB_U[r + 16 * j]; }
     }
-    float sta_inv[4] = { 0.0f, 0.0f, 0.0f, 0.0f };       // STA: float32 reciprocal of the number of used bins within +-2 of bin r + 16 j
-    if (STA) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            int cnt = 0;
-#pragma unroll
-            for (int dk = -2; dk <= 2; dk++) { const int k = r + 16 * j + dk; cnt += (k >= 6 && k <= 58 && k != 32); }
-            sta_inv[j] = cnt == 3 ? 0x1.555556p-2f : cnt == 4 ? 0.25f : 0x1.99999ap-3f;     // 1/3, 1/4, 1/5
-        }
-    }
+    // STA: the float32 reciprocal of the number of used bins within +-2 of bin r + 16 j is 1/5 but for eight bins next to the band
+    // edges and the unused centre bin -- formed where it is used from lane masks (scalar constants), not kept in four registers
+    // across the loops (the STA instance spilled inside its prefetch loops: tests/test_isa_prefetch_wait.py)
+    auto sta_inv_of = [&](int j) __attribute__((always_inline)) -> float {
+        // bins with three neighbours in the window: 6 (j 0, r 6), 58 (j 3, r 10); with four: 7; 30, 31; 33, 34; 57
+        const uint64_t m3 = j == 0 ? 0x0040ull : j == 3 ? 0x0400ull : 0ull;
+        const uint64_t m4 = j == 0 ? 0x0080ull : j == 1 ? 0xC000ull : j == 2 ? 0x0006ull : 0x0200ull;
+        float v = 0x1.99999ap-3f;                                                        // 1/5
+        v = __builtin_amdgcn_inverse_ballot_w64(m4 * 0x0001000100010001ull) ? 0.25f : v;
+        if (m3) v = __builtin_amdgcn_inverse_ballot_w64(m3 * 0x0001000100010001ull) ? 0x1.555556p-2f : v;      // 1/3
+        return v;
+    };
     int carrier0[4];                     // data carrier number 0..47 of bin r + 16 j, -1 for pilots / DC / guards
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -1359,7 +1389,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         {   // one rotation by the total offset (spec rule 8): the lane's base phasor from the exact integer phase at
             // s = 0, 1, 9, 17, ..., in between carried from symbol to symbol by exp(j theta 80); then steps of exp(j theta 16)
             if ((!DATA && s < 2) || ((s - 1) & 7) == 0) {        // wave-uniform
-                const unsigned long long ph = Qp * (unsigned long long)(unsigned)(off0 + r);
+                unsigned long long qp = Qp;
+                if (DATA && QP_LDS) { const uint2 q2 = *qpl; qp = ((unsigned long long)q2.y << 32) | q2.x; }
+                const unsigned long long ph = qp * (unsigned long long)(unsigned)(off0 + r);
                 sp_sincos_q((uint32_t)(ph >> 32), (uint32_t)ph, wbase.im, wbase.re);
             } else {
                 wbase = sp_cmul(wbase, u80);
@@ -1606,7 +1638,8 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                     const c32 sum = cadd(cadd(cadd(cadd(c32{ v0.x, v0.y }, c32{ v1.x, v1.y }), c32{ v2.x, v2.y }), c32{ v3.x, v3.y }),
                                          c32{ v4.x, v4.y });
                     const float2 o = Hl[64 * j];
-                    if (act && usedj) Hl[64 * j] = make_float2(0.5f * o.x + 0.5f * (sum.re * sta_inv[j]), 0.5f * o.y + 0.5f * (sum.im * sta_inv[j]));
+                    const float inv = sta_inv_of(j);
+                    if (act && usedj) Hl[64 * j] = make_float2(0.5f * o.x + 0.5f * (sum.re * inv), 0.5f * o.y + 0.5f * (sum.im * inv));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1661,7 +1694,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 const int q = s - 3;
                 const bool has_idx = idx_all != nullptr, has_car = car_all != nullptr;
                 int out_l = out;                                  // the row's plane words are addressed from the record index
-                asm volatile("" : "+v"(out_l));                   // every symbol anew: no loop-invariant pointer in registers
+                if (HB) asm volatile("" : "+v"(out_l));           // every symbol anew: no loop-invariant pointer in registers
                 const uint64_t act_m = __ballot(act);
                 // DATA: whether the rows with data symbols share a constellation was settled once (nbu_all > 0: they do)
                 // ... if not (rows of different rates and lengths), the rows that are left may still agree: the first active row's
@@ -1682,12 +1715,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                   if (HB) { __builtin_amdgcn_sched_barrier(0);                                                          \
                             store_hbits<NB>(Y, OK, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); } }
                 if (NBC != 0 && XC) {
-                    store_rows_x<(NBC ? NBC : 1)>(Y, carrier, act, q, idx, llr, car, x_idx, x_llr, x_car, x_csi, Wl, row_o, row_l, qlds, row, r);
+                    store_rows_x<(NBC ? NBC : 1), EQ != WIFIRX_EQ_LS>(Y, carrier, act, q, idx, llr, car, x_idx, x_llr, x_car, x_csi, Wl, row_o, row_l, qlds, row, r);
                     if (HB) { __builtin_amdgcn_sched_barrier(0);
                               store_hbits<(NBC ? NBC : 1)>(Y, act, q, hb_all + (size_t)(unsigned)out_l * (prm.max_sym * 12u), r); }
                 } else if (NBC != 0) {
                     if (WR_STORE_AS_LINES && (NBC <= 2 || (WR_STORE_AS_LINES > 2 && !COMB)) && (!HB || WR_STORE_AS_LINES > 1) && (PC || lines_ok))     // (a prefetch loop is entered only with lines_ok)
-                        store_bins_lines<(NBC ? NBC : 1)>(Y, carrier, act, q, idx, llr, row_o, row_l, qlds, row, r);
+                        store_bins_lines<(NBC ? NBC : 1), EQ != WIFIRX_EQ_LS>(Y, carrier, act, q, idx, llr, row_o, row_l, qlds, row, r);
                     else
                     store_bins<(NBC ? NBC : 1), false, true>(Y, carrier, act, q, idx, car, llr, true, false, true, w1, row_o, row_l);
                     if (HB) { __builtin_amdgcn_sched_barrier(0);
