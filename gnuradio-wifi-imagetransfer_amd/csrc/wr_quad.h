@@ -1295,6 +1295,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     uint32_t pf_voff0 = 0, pf_voff1 = 0;         // byte offsets of this lane's 16 bytes (frames 0 / 1 and 2 / 3) from pf_next
     const float2* pf_next = nullptr;             // wave-uniform: first sample of the NEXT symbol of the reference row
     int pf_end = 0;                              // the symbol index at which every row with data symbols ends
+    bool pf_row = false;                         // this row has data symbols (in a prefetch loop: the row is active in every iteration)
     int pf_nst = 0;                              // XK instances: global stores one symbol issues (wave-uniform, constant for the launch)
     // LDS byte address of the buffer and of its second half (wave-uniform: in scalar registers, whatever the compiler can prove)
     const uint32_t pf_m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(qlds + WR_QLDS_PF(QS)));
@@ -1312,6 +1313,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         const int first = (int)__builtin_ctzll(has_data);
         const bool mine = s_end > 3;
         pf_end = __builtin_amdgcn_readlane(s_end, first);
+        pf_row = mine;
         const uint64_t xbv = reinterpret_cast<uint64_t>(xb);
         const uint64_t xref = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(xbv >> 32), first) << 32) |
                               (uint32_t)__builtin_amdgcn_readlane((int)xbv, first);
@@ -1338,7 +1340,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         const int off0 = fs + ((!DATA && s < 2) ? 64 * s : 128 + 80 * (s - 2) + 16);
         bool act;
         if (DATA) {
-            act = s < s_end;                    // how far the row's frame goes was settled when the data symbols began
+            // how far the row's frame goes was settled when the data symbols began; in a prefetch loop every row with data symbols
+            // ends at the same symbol (pf_end, where the loop ends): which rows are active does not change from symbol to symbol
+            act = PC ? pf_row : s < s_end;
         } else {
             act = alive && (s <= n_sym + 2);
             if (act && (off0 + 64 > L || (s > 2 && (s - 3) >= (int)prm.max_sym))) {
@@ -1347,7 +1351,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                 act = false;
             }
         }
-        if (!__any(act)) return false;
+        if (!(DATA && PC) && !__any(act)) return false;       // (a prefetch loop runs to pf_end: a scalar bound, no vote per symbol)
 
         // ---- samples r + 16 j of the symbol (rows without a symbol get zeros) ----
         c32 v[4], cur[4];
@@ -1805,11 +1809,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             pf_nst = (x_llr ? nk : 0) + (x_idx ? 1 : 0) + (x_car ? 2 : 0) + (HB ? (nbu_all + 1) / 2 : 0);
         }
         typedef std::true_type with_px;
-        if (pfx && nbu_all == 1)           for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, with_px{}, s);
-        else if (pfx && nbu_all == 2)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, with_px{}, s);
+        if (pfx && nbu_all == 1)           { for (; s < pf_end; s++) (void)symbol(std::true_type{}, std::integral_constant<int, 1>{}, with_x{}, with_px{}, s); more = false; }
+        else if (pfx && nbu_all == 2)      { for (; s < pf_end; s++) (void)symbol(std::true_type{}, std::integral_constant<int, 2>{}, with_x{}, with_px{}, s); more = false; }
 #if WR_NB_LOOPS > 1
-        else if (!COMB && pfx && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, with_px{}, s);
-        else if (!COMB && pfx && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, with_px{}, s);
+        else if (!COMB && pfx && nbu_all == 4) { for (; s < pf_end; s++) (void)symbol(std::true_type{}, std::integral_constant<int, 4>{}, with_x{}, with_px{}, s); more = false; }
+        else if (!COMB && pfx && nbu_all == 6) { for (; s < pf_end; s++) (void)symbol(std::true_type{}, std::integral_constant<int, 6>{}, with_x{}, with_px{}, s); more = false; }
 #endif
         else
 #endif
@@ -1829,11 +1833,11 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         bool pf = false;
         if (special && (!COMB || nbu_all <= 2) && lines_ok) pf = pf_setup(has_data, s);        // wave-uniform
         typedef std::true_type with_p;
-        if (pf && nbu_all == 1)           for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 1>{}, no_x{}, with_p{}, s);
-        else if (pf && nbu_all == 2)      for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 2>{}, no_x{}, with_p{}, s);
+        if (pf && nbu_all == 1)           { for (; s < pf_end; s++) (void)symbol(std::true_type{}, std::integral_constant<int, 1>{}, no_x{}, with_p{}, s); more = false; }
+        else if (pf && nbu_all == 2)      { for (; s < pf_end; s++) (void)symbol(std::true_type{}, std::integral_constant<int, 2>{}, no_x{}, with_p{}, s); more = false; }
 #if WR_NB_LOOPS > 1
-        else if (!COMB && pf && nbu_all == 4) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 4>{}, no_x{}, with_p{}, s);
-        else if (!COMB && pf && nbu_all == 6) for (; more; s++) more = symbol(std::true_type{}, std::integral_constant<int, 6>{}, no_x{}, with_p{}, s);
+        else if (!COMB && pf && nbu_all == 4) { for (; s < pf_end; s++) (void)symbol(std::true_type{}, std::integral_constant<int, 4>{}, no_x{}, with_p{}, s); more = false; }
+        else if (!COMB && pf && nbu_all == 6) { for (; s < pf_end; s++) (void)symbol(std::true_type{}, std::integral_constant<int, 6>{}, no_x{}, with_p{}, s); more = false; }
 #endif
         else
 #endif

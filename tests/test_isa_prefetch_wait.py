@@ -88,6 +88,15 @@ def _prefetch_loops(fns):
                     t = _branch_target(ins[k][3])
                     if t is not None and t <= addr[d0]:
                         end, head = k, addr.index(t) if t in addr else None
+                        # (the loop may close with two branches to its head: one that skips a last store under an empty execution
+                        #  mask, then the store and the unconditional one)
+                        k2 = k + 1
+                        while k2 < min(end + 16, len(ins)):
+                            if ins[k2][1].startswith("s_cbranch") or ins[k2][1] == "s_branch":
+                                t2 = _branch_target(ins[k2][3])
+                                if t2 is not None and abs(t2 - t) <= 64 and t2 in addr:       # (a latch block of a few scalar moves in front of the head)
+                                    end, head = k2, min(head, addr.index(t2))
+                            k2 += 1
                         break
             if end is None or head is None:
                 continue                                  # pf_setup's request: straight-line code, followed by a full wait
@@ -113,12 +122,12 @@ def test_counted_waits_of_the_prefetch_loops(tmp_path):
     for name, eq, hb, kind, where, nst, younger, others, scratch in loops:
         assert younger >= nst, (name, where, "vmcnt(%d) with %d younger vector-memory instructions" % (nst, younger))
     # performance: nothing but the counted wait and no spill access in the loops -- asserted for every batch kernel (four equalisers,
-    # with and without plane output: what BASELINE's configurations and bench.py run) and the stream kernels but for two instances
+    # with and without plane output: what BASELINE's configurations and bench.py run) and the stream kernels but for the STA instances
     # that still spill inside a loop (listed, so that a change that adds to them is seen)
     dirty = {}
     for name, eq, hb, kind, where, nst, younger, others, scratch in loops:
         if others or scratch:
             dirty[(kind, eq, hb)] = dirty.get((kind, eq, hb), 0) + 1
-    known = {("stream", 2, 1): 2, ("stream", 3, 0): 1}
+    known = {("stream", 3, 0): 1, ("stream", 3, 1): 1}
     for key, n in dirty.items():
         assert key in known and n <= known[key], ("spill reload / full wait inside a prefetch loop", key, n, dirty)
