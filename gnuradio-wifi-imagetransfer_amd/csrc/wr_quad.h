@@ -1274,7 +1274,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     int pk = 0;                                                // (s - 2) mod 127: index into the pilot polarity sequence
     uint64_t polw = WR_POLARITY_NEG_LO;                        // ... or: the sequence from the current symbol on,
     int poln = 64;                                             //     the bits left in the window
-    bool polhi = false;                                        //     and which half of the 127 it came from
+    int polhi = 0;                                             //     and which half of the 127 it came from (scalar 0 / 1)
     (void)pk;
     float t4 = WR_T4_64F[0];                                   // float32 (2 pi s 80) / 64 of the current symbol
     const float* t4_next = WR_T4_64F + 1;                      // data loop: where the factor after next stands
@@ -1475,7 +1475,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
             // the polarity sequence as a window that moves one bit per symbol (two scalar shifts; refilled every 64 / 63 symbols)
             sgn = (uint32_t)polw << 31;
             polw >>= 1;
-            if (--poln == 0) { polhi = !polhi; polw = polhi ? WR_POLARITY_NEG_HI : WR_POLARITY_NEG_LO; poln = polhi ? 63 : 64; }
+            // (the refill -- every 64th / 63rd symbol -- as a branch the scalar unit almost never takes: written without the hint it
+            //  became ten always-executed scalar selects and a detour of the flag through a vector register per symbol)
+            if (__builtin_expect(--poln == 0, 0)) { polhi ^= 1; polw = polhi ? WR_POLARITY_NEG_HI : WR_POLARITY_NEG_LO; poln = 64 - polhi; }
 #else
             const uint64_t bits = pk < 64 ? (WR_POLARITY_NEG_LO >> pk) : (WR_POLARITY_NEG_HI >> (pk - 64));
             sgn = (uint32_t)(bits & 1ull) << 31;

@@ -128,6 +128,6 @@ def test_counted_waits_of_the_prefetch_loops(tmp_path):
     for name, eq, hb, kind, where, nst, younger, others, scratch in loops:
         if others or scratch:
             dirty[(kind, eq, hb)] = dirty.get((kind, eq, hb), 0) + 1
-    known = {("stream", 3, 0): 1, ("stream", 3, 1): 1}
+    known = {("batch", 3, 1): 1, ("stream", 3, 0): 1, ("stream", 3, 1): 1}      # STA: the 64-QAM loop
     for key, n in dirty.items():
         assert key in known and n <= known[key], ("spill reload / full wait inside a prefetch loop", key, n, dirty)
