@@ -284,6 +284,9 @@ def run_variant(torch, capi, txgen, orc, arena, name, enc, slot_len, n_frames, d
            "gsamples_per_s": float(n_frames) * slot_len / (kernel_ms * 1e-3) / 1e9,
            "algorithmic_bytes_per_frame": bpf, "frac": bpf * n_frames / (kernel_ms * 1e-3) / HBM_PEAK,
            "frames_complete": int(((fr["flags"] & capi.F_COMPLETE) != 0).sum())}
+    sync = (fr["flags"] & capi.F_SYNC) != 0
+    first_lts = (fr["trigger"].astype(np.int64) - 16 + fr["frame_start"])[sync]       # slot sample the long training symbols start at
+    res["frames_starting_on_a_line"] = float((first_lts % 16 == 0).mean()) if sync.any() else None
     res["ber_vs_tx"] = ber_vs_tx(torch, idx_t, fr, tx, n_bpsc, capi)
     if orc is not None and parity_frames > 0:
         n_p = min(parity_frames, n_frames)
@@ -867,6 +870,12 @@ def main():
                 V["config3_geometry"] = run_variant(torch, capi, txgen, orc, arena, "BASELINE.json configs[2] geometry: 64-QAM 3/4, slot 1472, "
                                                     "multipath taps tests/golden/sv_taps.npy (utils/SV_channel.py:81-86,128 draws), "
                                                     "LS, 20 dB", 7, 1472, taps=taps, cite="gnu_radio/IRS_AP.py:81,268-285", **kw)
+                # ... and the same geometry without the taps: under multipath the strongest LTS lag moves with the taps' delays and half of the
+                # frames no longer start on a 128-byte line (a row's 512 bytes of a symbol then straddle five lines, not four), on AWGN every
+                # frame does -- the difference between the two is the price of that, not of the LTS search (profiles/r05_preamble_analysis.txt)
+                V["config3_geometry_awgn"] = run_variant(torch, capi, txgen, orc, arena, "config-3 geometry on AWGN 20 dB (no taps): every frame "
+                                                         "starts on a 128-byte line", 7, 1472, yardstick=False, parity_frames=0,
+                                                         cite="gnu_radio/IRS_AP.py:81,268-285", **kw)
                 V["config1_geometry"] = run_variant(torch, capi, txgen, orc, arena, "BASELINE.json configs[0] geometry: BPSK 1/2, slot 8576, "
                                                     "AWGN 20 dB", 0, 8576, cite="gnu_radio/IRS_AP.py:268-285", **kw)
                 V["carrier_on"] = run_variant(torch, capi, txgen, orc, arena, "config 2 with the reference's own output set: equalised points "

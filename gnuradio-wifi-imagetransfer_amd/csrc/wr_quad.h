@@ -871,7 +871,9 @@ __device__ __forceinline__ void store_bins_lines(const c32 (&Y)[4], const int (&
             if (NB == 1)      *reinterpret_cast<float*>(lw) = Y[j].re;
             else if (NB == 2) *reinterpret_cast<float2*>(lw) = make_float2(Y[j].re, Y[j].im);
             else              *reinterpret_cast<float4*>(lw) = make_float4(Y[j].re, WR_T16_2 - __builtin_fabsf(Y[j].re), Y[j].im, WR_T16_2 - __builtin_fabsf(Y[j].im));
+#ifndef WR_DBG_NO_IDX_STAGING      // (measurement only: profiles/r05_lds_bank_conflicts.txt)
             *iw = decide(Y[j], NB);
+#endif
         }
     } else
 #endif
