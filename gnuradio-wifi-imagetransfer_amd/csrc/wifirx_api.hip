@@ -219,7 +219,13 @@ int wifirx_create(const wifirx_config* cfg, wifirx_handle** out)
     if (const char* e = std::getenv("WIFIRX_TEST_FAIL_CARRY")) h->test_fail_carry = std::atoi(e);
     if (const char* e = std::getenv("WIFIRX_TEST_DECODE_BUDGET")) h->test_decode_budget = (size_t)std::strtoull(e, nullptr, 10);
     if (const char* e = std::getenv("WIFIRX_TEST_FAIL_DECODE_SCRATCH")) h->test_fail_decode_scratch = std::atoi(e);
-    if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    // WIFIRX_STREAM_PRIORITY = high | low (environment; measurement: two handles whose kernels share the GPU, tools/coresident_probe.py)
+    int prio = 0, prio_lo = 0, prio_hi = 0;
+    if (const char* e = std::getenv("WIFIRX_STREAM_PRIORITY")) {
+        if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess) prio = e[0] == 'h' ? prio_hi : e[0] == 'l' ? prio_lo : 0;
+        else (void)hipGetLastError();
+    }
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio) != hipSuccess) {
         delete h;
         return fail(nullptr, WIFIRX_EHIP, "hipStreamCreate failed");
     }
