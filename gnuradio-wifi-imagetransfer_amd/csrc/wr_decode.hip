@@ -685,6 +685,9 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
 // ({3,2,1,0,7,6,5,4}[i]), stored inverted except for i = 0 and i = 4.
 #define WR_DQ_FRAMES    256
 #define WR_DQ_NORM      48
+#ifndef WR_DQ_SPEC_WAVES
+#define WR_DQ_SPEC_WAVES 2
+#endif
 #define WR_DQ_BYTE(h)   ((h) == 0 ? 0 : (h) == 1 ? 2 : (h) == 2 ? 1 : 3)
 
 __device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel)
@@ -856,13 +859,6 @@ __device__ __forceinline__ void spec_walk_group(SpecWalk& sw, int lane, const ui
                                                 uint32_t link_ref, int (&fb)[4])
 {
     const uint32_t* srow = surv + ((size_t)(sw.blk * 96 + 6 * sw.grp) * 64 + lane) * 8;
-    uint32_t l0[6], u0[6], l1[6], u1[6], l2[6], u2[6], l3[6], u3[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const uint4* sp = reinterpret_cast<const uint4*>(srow + (size_t)k * 512);
-        const uint4 a = sp[0], b = sp[1];
-        l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
-    }
 #pragma unroll
     for (int h = 0; h < 4; h++) {
         const uint32_t v = __builtin_bitreverse32((uint32_t)sw.st[h]) >> 26;      // u_(t-5) .. u_t, oldest in bit 0
@@ -870,14 +866,25 @@ __device__ __forceinline__ void spec_walk_group(SpecWalk& sw, int lane, const ui
         sw.aw[h][1] = __builtin_amdgcn_alignbit(sw.aw[h][1], sw.aw[h][0], 26);
         sw.aw[h][0] = (sw.aw[h][0] << 6) | v;
     }
+    // the six rows in two halves of three (24 registers in flight, not 48: the kernel runs at three waves per SIMD -- 168 registers)
 #pragma unroll
-    for (int q = 5; q >= 0; q--) {
-        const uint32_t h0 = WR_DQ_PICKP(sw.st[0], l0[q], u0[q]), h1 = WR_DQ_PICKP(sw.st[1], l1[q], u1[q]);
-        const uint32_t h2 = WR_DQ_PICKP(sw.st[2], l2[q], u2[q]), h3 = WR_DQ_PICKP(sw.st[3], l3[q], u3[q]);
-        sw.st[0] = (sw.st[0] >> 1) | (int)(h0 << 5);
-        sw.st[1] = (sw.st[1] >> 1) | (int)(h1 << 5);
-        sw.st[2] = (sw.st[2] >> 1) | (int)(h2 << 5);
-        sw.st[3] = (sw.st[3] >> 1) | (int)(h3 << 5);
+    for (int half = 1; half >= 0; half--) {
+        uint32_t l0[3], u0[3], l1[3], u1[3], l2[3], u2[3], l3[3], u3[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint4* sp = reinterpret_cast<const uint4*>(srow + (size_t)(3 * half + k) * 512);
+            const uint4 a = sp[0], b = sp[1];
+            l0[k] = a.x; u0[k] = b.x; l1[k] = a.z; u1[k] = b.z; l2[k] = a.y; u2[k] = b.y; l3[k] = a.w; u3[k] = b.w;
+        }
+#pragma unroll
+        for (int q = 2; q >= 0; q--) {
+            const uint32_t h0 = WR_DQ_PICKP(sw.st[0], l0[q], u0[q]), h1 = WR_DQ_PICKP(sw.st[1], l1[q], u1[q]);
+            const uint32_t h2 = WR_DQ_PICKP(sw.st[2], l2[q], u2[q]), h3 = WR_DQ_PICKP(sw.st[3], l3[q], u3[q]);
+            sw.st[0] = (sw.st[0] >> 1) | (int)(h0 << 5);
+            sw.st[1] = (sw.st[1] >> 1) | (int)(h1 << 5);
+            sw.st[2] = (sw.st[2] >> 1) | (int)(h2 << 5);
+            sw.st[3] = (sw.st[3] >> 1) | (int)(h3 << 5);
+        }
     }
     if (--sw.grp < 0) {
 #pragma unroll
@@ -895,7 +902,7 @@ __device__ __forceinline__ void spec_walk_group(SpecWalk& sw, int lane, const ui
 // MODE: 0 = a task's trace-back behind its add-compare-select; 1 = overlapped with the wave's next task (above); 2 = speculative
 // walks overlapped with the task's own add-compare-select (above).
 template <int ROWS, int MODE>        // LDS rows per wave: 32 (rates up to 16-QAM: 8 staged words x 4), 48 (64-QAM: one symbol of 12 words)
-__global__ __launch_bounds__(256, MODE ? 2 : (ROWS == 32 ? 4 : 3))
+__global__ __launch_bounds__(256, MODE == 2 ? WR_DQ_SPEC_WAVES : MODE ? 2 : (ROWS == 32 ? 4 : 3))
 void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
                      const uint32_t* __restrict__ hbits_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
                      uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total,

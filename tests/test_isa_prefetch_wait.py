@@ -30,8 +30,12 @@ def _disassemble(tmp):
     tools = [shutil.which("objcopy"), os.path.join(LLVM, "clang-offload-bundler"), os.path.join(LLVM, "llvm-objdump")]
     if not os.path.exists(LIB) or any(t is None or not os.path.exists(t) for t in tools):
         pytest.skip("libwifirx.so or the binutils / ROCm LLVM tools are not here")
-    fat = os.path.join(tmp, "fat.bin")
-    subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, LIB], stderr=subprocess.DEVNULL)
+    # (on a COPY, with an explicit output file: objcopy without one rewrites its INPUT in place -- the library some earlier test of
+    #  this process has mapped; the suite then died later with a segmentation fault in whatever native code ran next)
+    fat, lib_copy = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "libwifirx_copy.so")
+    shutil.copyfile(LIB, lib_copy)
+    subprocess.check_call([tools[0], "--dump-section", ".hip_fatbin=" + fat, lib_copy, os.path.join(tmp, "objcopy_out.so")],
+                          stderr=subprocess.DEVNULL)
     # one bundle per translation unit, back to back
     data = open(fat, "rb").read()
     starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
@@ -115,8 +119,9 @@ def _prefetch_loops(fns):
     return out
 
 
-def test_counted_waits_of_the_prefetch_loops(tmp_path):
-    loops = _prefetch_loops(_functions(_disassemble(str(tmp_path))))
+def check(tmp):
+    """the assertions; run in a process of its own (see the test below)"""
+    loops = _prefetch_loops(_functions(_disassemble(tmp)))
     assert len(loops) >= 8 * 2 * 2 - 8                 # four equalisers x planes on / off x batch / stream, 2 .. 4 loops each
     # correctness, every instance: at least as many younger vector-memory instructions as the wait leaves outstanding
     for name, eq, hb, kind, where, nst, younger, others, scratch in loops:
@@ -131,3 +136,27 @@ def test_counted_waits_of_the_prefetch_loops(tmp_path):
     known = {("batch", 3, 1): 1, ("stream", 3, 0): 1, ("stream", 3, 1): 1}      # STA: the 64-QAM loop
     for key, n in dirty.items():
         assert key in known and n <= known[key], ("spill reload / full wait inside a prefetch loop", key, n, dirty)
+    return len(loops)
+
+
+def test_counted_waits_of_the_prefetch_loops(tmp_path):
+    """Runs check() in a child interpreter (400 000 lines of disassembly parsed outside the pytest process); a failed assertion
+    arrives as the child's traceback."""
+    import sys
+    if not os.path.exists(LIB):
+        pytest.skip("libwifirx.so not built")
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    if p.returncode == 77:
+        pytest.skip(p.stdout.strip() or "tools missing")
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-3000:])
+    assert "prefetch loops checked" in p.stdout
+
+
+if __name__ == "__main__":
+    import sys
+    try:
+        n = check(sys.argv[1])
+    except pytest.skip.Exception as e:          # tools not here
+        print(e)
+        sys.exit(77)
+    print("%d prefetch loops checked" % n)
