@@ -685,9 +685,7 @@ void decode_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict_
 // ({3,2,1,0,7,6,5,4}[i]), stored inverted except for i = 0 and i = 4.
 #define WR_DQ_FRAMES    256
 #define WR_DQ_NORM      48
-#ifndef WR_DQ_SPEC_WAVES
-#define WR_DQ_SPEC_WAVES 2
-#endif
+// (WR_DQ_SPEC_WAVES -- waves per SIMD of the speculative-trace-back instances -- is in wr_kernels.h: the host sizes the launch by it)
 #define WR_DQ_BYTE(h)   ((h) == 0 ? 0 : (h) == 1 ? 2 : (h) == 2 ? 1 : 3)
 
 __device__ __forceinline__ uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel)
@@ -902,7 +900,7 @@ __device__ __forceinline__ void spec_walk_group(SpecWalk& sw, int lane, const ui
 // MODE: 0 = a task's trace-back behind its add-compare-select; 1 = overlapped with the wave's next task (above); 2 = speculative
 // walks overlapped with the task's own add-compare-select (above).
 template <int ROWS, int MODE>        // LDS rows per wave: 32 (rates up to 16-QAM: 8 staged words x 4), 48 (64-QAM: one symbol of 12 words)
-__global__ __launch_bounds__(256, MODE == 2 ? WR_DQ_SPEC_WAVES : MODE ? 2 : (ROWS == 32 ? 4 : 3))
+__global__ __launch_bounds__(256, MODE == 2 ? (ROWS == 32 ? WR_DQ_SPEC_WAVES : 2) : MODE ? 2 : (ROWS == 32 ? 4 : 3))      // (48 rows: 52.5 kB of LDS per workgroup -- two fit a CU anyway)
 void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restrict__ frames,
                      const uint32_t* __restrict__ hbits_all, uint8_t* __restrict__ psdu_all, uint32_t psdu_stride,
                      uint8_t* __restrict__ scratch, size_t scratch_stride, uint32_t n_steps_cap, uint32_t n_waves_total,

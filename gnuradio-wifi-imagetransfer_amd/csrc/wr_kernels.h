@@ -16,6 +16,11 @@
 #endif
 #define WR_STREAM_SPAN     16       // tiles of 64 samples one wave scans in stream-mode detection
 #define WR_DECODE_MAX_WAVES 4096    // waves of the decode kernel (grid-stride; each owns a scratch slice)
+#ifndef WR_DQ_SPEC_WAVES
+#define WR_DQ_SPEC_WAVES 3          // decode_q_kernel with the speculative trace-back (rates up to 16-QAM): waves per SIMD.  3 = 168 registers,
+                                    // 62 spilled but 9 accesses inside the group loop of 6 300 instructions: 12.6 -> 11.45 ms per million frames
+                                    // (2: 231 registers, no spill; 4: 128 registers, 202 spilled, 14.7 ms) -- profiles/r05_ab_decode_waves.txt
+#endif
 #define WR_DECODE_SMALL_MAX 16384      // batches up to this many frames take the wave-per-frame decode kernel
 #define WR_DECODE_FRAMES_PER_WAVE 128   // two frames per lane: packed 16-bit path metrics
 #define WR_DECODE_Q_FRAMES_PER_WAVE 256 // four frames per lane: byte path metrics (decode_q_kernel)
