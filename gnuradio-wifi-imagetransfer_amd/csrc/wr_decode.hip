@@ -721,6 +721,26 @@ __device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t m, uint32_t b)
     return r;
 }
 
+// The state with the smallest path metric of each of the four frames of a lane, lowest state on ties (register phase 0: pm[s] is
+// state s; byte WR_DQ_BYTE(h) of a register = frame h).  Keys (metric << 6 | state) of two frames side by side in the 16-bit
+// halves of a register -- bytes 0 / 2 = frames h = 0 / 1, bytes 1 / 3 = h = 2 / 3; a metric is below 128, a key below 2^13 --
+// and one packed 16-bit minimum per pair and state: 7 instructions per state for four frames (the byte-by-byte search -- extract,
+// compare, two selects per frame -- took 12 and as many wait states).
+__device__ __forceinline__ void best_states4(const uint32_t (&pm)[64], int (&bs)[4])
+{
+    uint32_t k01 = 0xffffffffu, k23 = 0xffffffffu;
+#pragma unroll
+    for (int s2 = 0; s2 < 64; s2++) {
+        const uint32_t st2 = (uint32_t)s2 * 0x00010001u;
+        const uint32_t a = ((pm[s2] & 0x00ff00ffu) << 6) | st2;
+        const uint32_t b = (((pm[s2] >> 8) & 0x00ff00ffu) << 6) | st2;
+        k01 = pk_min(k01, a);
+        k23 = pk_min(k23, b);
+    }
+    bs[0] = (int)(k01 & 63u); bs[1] = (int)((k01 >> 16) & 63u);
+    bs[2] = (int)(k23 & 63u); bs[3] = (int)((k23 >> 16) & 63u);
+}
+
 // One trellis step at register phase P.  The survivor words leave in two halves (states 0..31 after the butterflies
 // 0..15, states 32..63 after 16..31), each transposed to per-frame words right away: four accumulators live at a time.
 template <int P>
@@ -1094,19 +1114,11 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
                 for (int h = 0; h < 4; h++) { endh[h] = tg < n_data[h] && tg + 6 == n_data[h]; any_end |= endh[h]; }
                 if (__any(any_end)) {
                     // a frame just ended (register phase 0 again): smallest metric, lowest state
+                    int bs4[4];
+                    best_states4(pm, bs4);
 #pragma unroll
-                    for (int h = 0; h < 4; h++) {
-                        if (!__any(endh[h])) continue;
-                        const int sh = 8 * WR_DQ_BYTE(h);
-                        uint32_t bm = (pm[0] >> sh) & 0xffu;
-                        int bs = 0;
-#pragma unroll
-                        for (int s2 = 1; s2 < 64; s2++) {
-                            const uint32_t v = (pm[s2] >> sh) & 0xffu;
-                            if (v < bm) { bm = v; bs = s2; }
-                        }
-                        if (endh[h]) best[h] = bs;
-                    }
+                    for (int h = 0; h < 4; h++)
+                        if (endh[h]) best[h] = bs4[h];
                 }
             }
             tt_u += 6;
@@ -1118,18 +1130,12 @@ void decode_q_kernel(uint32_t n_slots, uint32_t max_sym, wifirx_frame* __restric
                     // boundary B_j, j = done / 96, with another whole block of trellis steps ahead: the walk through block j - 1
                     // starts in the state with the smallest metric (register phase 0: pm[s] is state s)
                     uint32_t S = 0u;
+                    int bs4[4];
+                    best_states4(pm, bs4);
 #pragma unroll
                     for (int h = 0; h < 4; h++) {
-                        const int sh = 8 * WR_DQ_BYTE(h);
-                        uint32_t bm = (pm[0] >> sh) & 0xffu;
-                        int bs = 0;
-#pragma unroll
-                        for (int s2 = 1; s2 < 64; s2++) {
-                            const uint32_t v = (pm[s2] >> sh) & 0xffu;
-                            if (v < bm) { bm = v; bs = s2; }
-                        }
-                        sw.st[h] = bs;
-                        S |= (uint32_t)bs << (8 * h);
+                        sw.st[h] = bs4[h];
+                        S |= (uint32_t)bs4[h] << (8 * h);
 #pragma unroll
                         for (int w = 0; w < 3; w++) sw.aw[h][w] = 0u;
                     }
