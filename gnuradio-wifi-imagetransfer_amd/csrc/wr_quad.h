@@ -1772,6 +1772,9 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         typedef std::false_type no_x;
         typedef std::false_type no_p;
         for (; more && s < 3; s++) more = symbol(std::false_type{}, nb_any{}, no_x{}, no_p{}, s);
+#if defined(WR_ABLATE) && WR_ABLATE == 3      // timing experiment: preamble + the two LTS symbols + SIGNAL, no data symbol
+        more = false;
+#endif
 #if WR_SPLIT_SYMBOL_LOOP
         uint64_t has_data = 0;
         if (more) {
