@@ -155,36 +155,46 @@ __device__ __forceinline__ uint8_t decide(c32 y, int n_bpsc)
 // bit t), wave-uniform.  The path metrics of the four frames share one register per lane, a byte each: a metric is at most
 // 48, and the "unreachable" start value only has to exceed that (64; the oracle's 2^28 orders every comparison the same
 // way: each path has one origin) -- so no byte ever reaches 128 and the byte-wise compare is one subtraction with a guard
-// bit: byte f of (m0 + 0x7f7f7f7f) - m1 has its top bit set iff m1 < m0.  Survivor words go through `scr` (4 x 24 x 8 B of
-// wave-private LDS); the trace-back runs in lanes 0..3, one frame each.
+// bit: byte f of (m0 + 0x7f7f7f7f) - m1 has its top bit set iff m1 < m0.  Survivor bits stay in the lane of their state (below);
+// the trace-back runs in lanes 0..3, one frame each.
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-__device__ __forceinline__ void viterbi_signal4(const uint64_t (&cb)[4], int lane, uint64_t* scr, uint32_t (&sig)[4])
+__device__ __forceinline__ void viterbi_signal4(const uint64_t (&cb)[4], int lane, uint32_t (&sig)[4])
 {
     const int s = lane, u = s & 1, p0 = s >> 1, p1 = (s >> 1) | 32;
-    const int f0 = (p0 << 1) | u, f1 = (p1 << 1) | u;
+    // the branch bits of the transition p0 -> s; those of p1 -> s are their complements (bit 6 is a tap of both generators:
+    // 0155, 0117), so its branch metric is 2 - (that of p0 -> s) in every byte
+    const int f0 = (p0 << 1) | u;
     const uint32_t A0 = (__builtin_popcount(f0 & 0155) & 1) * 0x01010101u, B0 = (__builtin_popcount(f0 & 0117) & 1) * 0x01010101u;
-    const uint32_t A1 = (__builtin_popcount(f1 & 0155) & 1) * 0x01010101u, B1 = (__builtin_popcount(f1 & 0117) & 1) * 0x01010101u;
     uint32_t pm = (s == 0) ? 0u : 0x40404040u;
-    // received bits, frame f in byte f: lane t forms those of step t once, the loop fetches them with two lane reads
-    uint32_t ra_l = 0, rb_l = 0;
+    // received bits, frame f in byte f (bit 0: first coded bit of the step, bit 1: second): lane t forms those of step t once, the
+    // loop fetches them with one lane read and splits them on the scalar side
+    uint32_t r2_l = 0;
 #pragma unroll
-    for (int f = 0; f < 4; f++) {
-        const uint32_t two = (uint32_t)(cb[f] >> (2 * (lane & 31))) & 3u;
-        ra_l |= (two & 1u) << (8 * f);
-        rb_l |= (two >> 1) << (8 * f);
-    }
+    for (int f = 0; f < 4; f++) r2_l |= ((uint32_t)(cb[f] >> (2 * (lane & 31))) & 3u) << (8 * f);
+    // Survivor bits (round 5): every lane = state keeps ITS OWN decisions, byte f of a word = frame f, bit i = step 8 k + i -- two
+    // instructions per step.  (Until round 5: four ballots per step and lane 0 writing four 64-bit words to LDS -- 24 instructions
+    // per step, half of the decoder's.)  The trace-back fetches the word of the state it stands in across the lanes.  Three rounds
+    // of eight steps, NOT unrolled across the rounds: fully unrolled, the scheduler hoists the 48 lane reads to the front and the
+    // scalar registers they need spill into vector lanes of the whole kernel (scratch 24 -> 44 bytes in the LS instance).
+    uint32_t h0 = 0u, h1 = 0u, h2 = 0u;                                    // steps 16..23, 8..15, 0..7 after the loop
 #pragma unroll 1
-    for (int t = 0; t < 24; t++) {
-        const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane((int)ra_l, t), rb = (uint32_t)__builtin_amdgcn_readlane((int)rb_l, t);
-        const uint32_t m0 = (uint32_t)__shfl((int)pm, p0, 64) + ((ra ^ A0) + (rb ^ B0));
-        const uint32_t m1 = (uint32_t)__shfl((int)pm, p1, 64) + ((ra ^ A1) + (rb ^ B1));
-        const uint32_t top = ((m0 + 0x7f7f7f7fu) - m1) & 0x80808080u;     // byte f: 0x80 iff m1 < m0
-        const uint32_t mask = (top - (top >> 7)) | top;                   // ... 0xff
-        pm = (m1 & mask) | (m0 & ~mask);
-        const uint64_t d0 = __ballot((top & 0x00000080u) != 0), d1 = __ballot((top & 0x00008000u) != 0);
-        const uint64_t d2 = __ballot((top & 0x00800000u) != 0), d3 = __ballot((top & 0x80000000u) != 0);
-        if (lane == 0) { scr[t] = d0; scr[24 + t] = d1; scr[48 + t] = d2; scr[72 + t] = d3; }
+    for (int k = 0; k < 3; k++) {
+        uint32_t acc = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int t = 8 * k + i;
+            const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)r2_l, t);
+            const uint32_t ra = r2 & 0x01010101u, rb = (r2 >> 1) & 0x01010101u;
+            const uint32_t x0 = (ra ^ A0) + (rb ^ B0);
+            const uint32_t m0 = (uint32_t)__shfl((int)pm, p0, 64) + x0;
+            const uint32_t m1 = (uint32_t)__shfl((int)pm, p1, 64) + (0x02020202u - x0);
+            const uint32_t top = ((m0 + 0x7f7f7f7fu) - m1) & 0x80808080u;     // byte f: 0x80 iff m1 < m0
+            const uint32_t mask = (top - (top >> 7)) | top;                   // ... 0xff
+            pm = (m1 & mask) | (m0 & ~mask);
+            acc |= top >> (7 - i);
+        }
+        h2 = h1; h1 = h0; h0 = acc;
     }
     // best final state per frame: smallest metric, lowest index on ties -- keys (metric << 6 | state) of two frames per register
     uint32_t k01 = ((((pm & 0xffu) << 6) | (uint32_t)s)) | (((((pm >> 8) & 0xffu) << 6) | (uint32_t)s) << 16);
@@ -194,20 +204,24 @@ __device__ __forceinline__ void viterbi_signal4(const uint64_t (&cb)[4], int lan
         k01 = pk_min_u16(k01, (uint32_t)__shfl_xor((int)k01, k, 64));
         k23 = pk_min_u16(k23, (uint32_t)__shfl_xor((int)k23, k, 64));
     }
-    __builtin_amdgcn_wave_barrier();
     // trace-back: lane f = frame f (the other lanes repeat frames 0..3 and are not read)
     const int fr = lane & 3;
     const uint32_t kk = (fr & 2) ? k23 : k01;
     int st = (int)(((fr & 1) ? (kk >> 16) : kk) & 63u);
-    const uint64_t* row = scr + 24 * fr;
     uint32_t bits = 0;
-#pragma unroll 6
-    for (int t = 23; t >= 0; t--) {
-        bits |= (uint32_t)(st & 1) << t;
-        const uint32_t h = (uint32_t)(row[t] >> st) & 1u;
-        st = (st >> 1) | (int)(h << 5);
+#pragma unroll 1
+    for (int k = 2; k >= 0; k--) {
+        uint32_t b8 = 0;
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            b8 |= (uint32_t)(st & 1) << i;
+            const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * st, (int)h0);      // the decisions of state st
+            const uint32_t h = (w >> (8 * fr + i)) & 1u;
+            st = (st >> 1) | (int)(h << 5);
+        }
+        bits |= b8 << (8 * k);
+        h0 = h1; h1 = h2;
     }
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int f = 0; f < 4; f++) sig[f] = (uint32_t)__builtin_amdgcn_readlane((int)bits, f);
 }
@@ -885,7 +899,21 @@ __device__ __forceinline__ void store_bins_lines(const c32 (&Y)[4], const int (&
         if (NB == 1)      *reinterpret_cast<float*>(srow + 4 * carrier[j]) = Y[j].re;
         else if (NB == 2) *reinterpret_cast<float2*>(srow + 8 * carrier[j]) = make_float2(Y[j].re, Y[j].im);
         else if (NB == 4) *reinterpret_cast<float4*>(srow + 16 * carrier[j]) = make_float4(Y[j].re, WR_T16_2 - are, Y[j].im, WR_T16_2 - aim);
-        else {
+        else if (OFF32) {
+            // ONE lane constant per bin, ci = carrier + 48 row: the decision goes to byte IDX0 + ci and the LLRs to byte 24 ci
+            // (ROWB = 24 x 48) -- the product formed HERE, by an instruction the compiler cannot hoist.  As two lane constants
+            // per bin (eight registers across the 64-QAM loop) one of them was spilled in the LMS / STA instances, and its reload
+            // inside the loop is a vector memory operation the counted wait of the prefetch cannot skip.
+            const uint32_t ci = (uint32_t)(carrier[j] + 48 * row);
+            uint32_t l24;
+            asm volatile("v_mul_u32_u24 %0, 24, %1" : "=v"(l24) : "v"(ci));
+            float2* l2 = reinterpret_cast<float2*>(reinterpret_cast<char*>(stage) + l24);
+            l2[0] = make_float2(Y[j].re, WR_T64_4 - are);
+            l2[1] = make_float2(WR_T64_2 - __builtin_fabsf(are - WR_T64_4), Y[j].im);
+            l2[2] = make_float2(WR_T64_4 - aim, WR_T64_2 - __builtin_fabsf(aim - WR_T64_4));
+            reinterpret_cast<uint8_t*>(stage)[IDX0 + ci] = decide(Y[j], NB);
+            continue;
+        } else {
             float2* l2 = reinterpret_cast<float2*>(srow + 24 * carrier[j]);
             l2[0] = make_float2(Y[j].re, WR_T64_4 - are);
             l2[1] = make_float2(WR_T64_2 - __builtin_fabsf(are - WR_T64_4), Y[j].im);
@@ -1253,10 +1281,19 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
     }
     __builtin_amdgcn_wave_barrier();
     // LDS transposes (8-byte elements).  Element (hi, mid, lo) of a row lives at
-    //   128*(row>>1) + 32*hi + 16*(row&1) + 4*mid + (hi ^ lo):
-    // the 32 lanes of a row pair hit 32 different 8-byte banks both when a register index is fixed and
-    // the lane pair (mid, lo) varies and when lo is fixed and (hi, mid) varies.
-    float2* ql = reinterpret_cast<float2*>(qlds) + 128 * (row >> 1) + 16 * (row & 1);
+    //   TP_PAD:  144*row + 33*hi + 4*mid + lo            (round 5; every instance but COMB, whose scratch area is too short)
+    //   else:    128*(row>>1) + 32*hi + 16*(row&1) + 4*mid + (hi ^ lo)
+    // Either way the 32 lanes of a row pair hit 32 different 8-byte banks both when a register index is fixed and the lane pair
+    // (mid, lo) varies and when lo is fixed and (hi, mid) varies.  The xor swizzle pays for that with an address register per
+    // access (the offset of register j is not a constant: 16 registers across the symbol loops); with the PADDING -- a stride of 33
+    // between the hi-planes, 144 between rows (= 16 banks apart modulo 32) -- the four accesses of a phase are ONE lane address +
+    // constants: four address registers instead of sixteen, and the accesses pair into ds_write2_b64 / ds_read2_b64 (eight LDS
+    // instructions fewer per symbol).  4 x 144 x 8 = 4 608 bytes of the scratch area (4 800).
+    #ifndef WR_TP_PAD
+#define WR_TP_PAD 1
+#endif
+    constexpr bool TP_PAD = WR_TP_PAD && EQ != WIFIRX_EQ_COMB;
+    float2* ql = reinterpret_cast<float2*>(qlds) + (TP_PAD ? 144 * row : 128 * (row >> 1) + 16 * (row & 1));
     const int m4 = 4 * (r & 3), c2 = r >> 2;
     // transpose A: stage-1 output q of lane r=(m, c) is element (q, m, c); lane (q1=c2, m) reads (q1, m, j)
     // transpose B: stage-2 output q2 of lane (q1=c2, m) is element (q2, q1, m); lane (q1=r&3, q2=c2) reads (q2, q1, j)
@@ -1417,12 +1454,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         for (int j = 0; j < 4; j++) {
             c32 y = v[0];
             if (j) { float2 w = twl[(j - 1) * 16 + r]; y = sp_cmul(v[j], c32{ w.x, w.y }); }
-            ql[32 * j + m4 + (j ^ c2)] = make_float2(y.re, y.im);
+            ql[TP_PAD ? 33 * j + m4 + c2 : 32 * j + m4 + (j ^ c2)] = make_float2(y.re, y.im);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            float2 t = ql[32 * c2 + m4 + (c2 ^ j)];
+            float2 t = ql[TP_PAD ? 33 * c2 + m4 + j : 32 * c2 + m4 + (c2 ^ j)];
             v[j] = { t.x, t.y };
         }
         __builtin_amdgcn_wave_barrier();
@@ -1431,12 +1468,12 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
         for (int j = 0; j < 4; j++) {
             c32 y = v[0];
             if (j) { float2 w = twl[(j + 2) * 16 + r]; y = sp_cmul(v[j], c32{ w.x, w.y }); }
-            ql[32 * j + 4 * c2 + (j ^ (r & 3))] = make_float2(y.re, y.im);
+            ql[TP_PAD ? 33 * j + 4 * c2 + (r & 3) : 32 * j + 4 * c2 + (j ^ (r & 3))] = make_float2(y.re, y.im);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            float2 t = ql[32 * c2 + m4 + (c2 ^ j)];
+            float2 t = ql[TP_PAD ? 33 * c2 + m4 + j : 32 * c2 + m4 + (c2 ^ j)];
             v[j] = { t.x, t.y };
         }
         __builtin_amdgcn_wave_barrier();
@@ -1671,7 +1708,7 @@ __device__ __forceinline__ void frames_quad(const QuadSeed& seed, const DemodPar
                     de[f] = __ballot(((cm >> dsrc) & 1ull) != 0);
                 }
                 uint32_t sig4[4];
-                viterbi_signal4(de, lane, reinterpret_cast<uint64_t*>(qlds), sig4);
+                viterbi_signal4(de, lane, sig4);
 #pragma unroll
                 for (int f = 0; f < 4; f++) {
                     if (!((actmask >> (16 * f)) & 1)) continue;
