@@ -241,7 +241,7 @@ class VariantArena:
 
 def run_variant(torch, capi, txgen, orc, arena, name, enc, slot_len, n_frames, device, chan_est=0, want_carrier=False,
                 taps=None, snr_db=SNR_DB, cfo_max=CFO_MAX, n_templates=256, seed=4321, cores=1, yardstick=True,
-                parity_frames=4096, cite=""):
+                parity_frames=4096, cite="", lead=LEAD):
     """One more geometry / output set / equaliser through the same timed kernel: device-resident batch made like the
     headline's (host templates -> Philox AWGN + CFO on the device), kernel time by HIP events (mean of 3 after a warm-up),
     roofline fraction on SURVEY.md 8(d)'s bytes (carrier rows included when on), channel BER, parity of the first frames
@@ -256,13 +256,13 @@ def run_variant(torch, capi, txgen, orc, arena, name, enc, slot_len, n_frames, d
             samples = txgen.impair(tx.samples, None, cfo=0.0, lead=0, total=tx.samples.shape[1] + taps.shape[1], taps=taps[:n_templates])
         arena.tx[key] = (tx, samples)
     tx, samples = arena.tx[key]
-    assert LEAD + samples.shape[1] <= slot_len
+    assert lead + samples.shape[1] <= slot_len
     rx = capi.WifiRx(bandwidth=BANDWIDTH, frequency=FREQUENCY, sensitivity=0.56, chan_est=chan_est, max_sym=n_sym,
                      llr_bits=n_bpsc, want_carrier=want_carrier, device=device)
     iq, frames_t, idx_t, llr_t, car_t = arena.views(slot_len, n_sym, n_bpsc, want_carrier)
-    skey = key + (slot_len, snr_db, float(cfo_max))
+    skey = key + (slot_len, snr_db, float(cfo_max), lead)
     if arena.synth_key != skey:      # (the box yardstick only reads the samples: a batch stays valid for the next variant on it)
-        rx.synth_slots(samples, iq.data_ptr(), slot_len, n_frames, LEAD, snr_db, float(cfo_max), seed)
+        rx.synth_slots(samples, iq.data_ptr(), slot_len, n_frames, lead, snr_db, float(cfo_max), seed)
         arena.synth_key = skey
     torch.cuda.synchronize()
     out = capi.Out(frames_t.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), car_t.data_ptr() if want_carrier else None,
@@ -300,7 +300,7 @@ def run_variant(torch, capi, txgen, orc, arena, name, enc, slot_len, n_frames, d
         res["parity"] = {"frames_checked": n_p, "mismatching_values": mism}
     if yardstick:
         box = box_yardstick(iq.data_ptr(), idx_t.data_ptr(), llr_t.data_ptr(), car_t.data_ptr() if want_carrier else None,
-                            n_frames, slot_len, LEAD, n_sym, n_bpsc, reps=2)
+                            n_frames, slot_len, lead, n_sym, n_bpsc, reps=2)
         res["box"] = box
         if box.get("available"):
             res["kernel_vs_box_floor"] = kernel_ms / box["mem_floor_ms"]
@@ -870,12 +870,20 @@ def main():
                 V["config3_geometry"] = run_variant(torch, capi, txgen, orc, arena, "BASELINE.json configs[2] geometry: 64-QAM 3/4, slot 1472, "
                                                     "multipath taps tests/golden/sv_taps.npy (utils/SV_channel.py:81-86,128 draws), "
                                                     "LS, 20 dB", 7, 1472, taps=taps, cite="gnu_radio/IRS_AP.py:81,268-285", **kw)
-                # ... and the same geometry without the taps: under multipath the strongest LTS lag moves with the taps' delays and half of the
-                # frames no longer start on a 128-byte line (a row's 512 bytes of a symbol then straddle five lines, not four), on AWGN every
-                # frame does -- the difference between the two is the price of that, not of the LTS search (profiles/r05_preamble_analysis.txt)
+                # ... and the same geometry without the taps.  What the taps cost is the LTS search (eight candidates instead of two when the
+                # third largest lag is close to the second: +0.3 ms in the preamble phase alone), not the frames' alignment (under multipath
+                # half of them no longer start on a 128-byte line; the config-3 geometry, bound by instruction issue in front of the data
+                # symbols, loses 1-2 % to that: profiles/r05_preamble_analysis.txt).  The alignment is what `config2_off_line` prices.
                 V["config3_geometry_awgn"] = run_variant(torch, capi, txgen, orc, arena, "config-3 geometry on AWGN 20 dB (no taps): every frame "
                                                          "starts on a 128-byte line", 7, 1472, yardstick=False, parity_frames=0,
                                                          cite="gnu_radio/IRS_AP.py:81,268-285", **kw)
+                # config 2 with every frame three samples (24 bytes) off the 128-byte grid: a row's 512 bytes of a symbol straddle five
+                # lines, and the line with the cyclic prefix -- skipped when frames start on a line -- is fetched too (+25 % sample traffic).
+                # A recording has no alignment at all; BASELINE's synthetic slots (lead 160 samples = ten lines) are the best case.
+                V["config2_off_line"] = run_variant(torch, capi, txgen, orc, arena, "config 2 with a lead of %d samples: no frame starts on a "
+                                                    "128-byte line" % (LEAD + 3), ENCODING, SLOT_LEN, yardstick=False, parity_frames=1024,
+                                                    cite="gnu_radio/IRS_AP.py:268-285", lead=LEAD + 3, **kw)
+                V["config2_off_line"]["vs_headline_same_run"] = V["config2_off_line"]["kernel_ms"] / kernel_ms_avg
                 V["config1_geometry"] = run_variant(torch, capi, txgen, orc, arena, "BASELINE.json configs[0] geometry: BPSK 1/2, slot 8576, "
                                                     "AWGN 20 dB", 0, 8576, cite="gnu_radio/IRS_AP.py:268-285", **kw)
                 V["carrier_on"] = run_variant(torch, capi, txgen, orc, arena, "config 2 with the reference's own output set: equalised points "

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--stats", action="store_true", help="the probe's moments (sym_stats)")
     ap.add_argument("--sv", action="store_true", help="multipath on the templates (tests/golden/sv_taps.npy: bench.py's config3_geometry)")
     ap.add_argument("--snr", type=float, default=None)
+    ap.add_argument("--lead", type=int, default=160, help="noise samples in front of every frame (160 = ten 128-byte lines: frames start on a line)")
     a = ap.parse_args()
     from wifirx import txgen
     enc, slot, snr = {2: (2, 4608, 20.0), 3: (7, 1472, 30.0), 1: (0, 8576, 20.0)}[a.geometry]
@@ -63,7 +64,7 @@ def main():
     m0, rx0 = mods[0], rxs[0]
     n = a.frames
     iq = rx0.alloc(n * slot * 8)
-    rx0.synth_slots(samples, iq.ptr, slot, n, 160, snr, 0.037, 99)
+    rx0.synth_slots(samples, iq.ptr, slot, n, a.lead, snr, 0.037, 99)
     planes = a.planes or a.planes_only
     dev = rx0.alloc_out(n, want_hbits=planes, want_stats=a.stats)
     rx0.sync()
